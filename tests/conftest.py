@@ -1,0 +1,45 @@
+"""pytest configuration: ``gpu`` marker + shared helpers.
+
+``-m "not gpu"`` runs everywhere (oracle vs golden fixtures, host logic, C-ABI
+symbol check, gloo world_size-2 slab tests); ``-m gpu`` are the parity tests
+proper and call the HIP engine through the C-ABI on a real MI355X.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def golden(name):
+    """Load tests/golden/<name>.npz as a dict of numpy arrays."""
+    with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def unpack_nsm(g):
+    shape = tuple(int(s) for s in g["no_streaming_mask_shape"])
+    n = int(np.prod(shape))
+    return np.unpackbits(g["no_streaming_mask"])[:n].reshape(shape).astype(np.uint8)
+
+
+TORCH_DT = {"f64": torch.float64, "f32": torch.float32}

@@ -1,0 +1,176 @@
+"""Pin the CPU oracle (oracle/lettuce_oracle.py) against vectors produced by the
+reference's own PyTorch CPU path (tests/golden, made by oracle/gen_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, unpack_nsm, TORCH_DT
+from oracle import lettuce_oracle as orc
+
+# the oracle mirrors the reference op for op; fp64 agreement is at rounding level
+TOL = {"f64": dict(rtol=0, atol=2e-14), "f32": dict(rtol=0, atol=2e-6)}
+
+
+def close(a, b, dt, scale=1.0):
+    tol = TOL[dt]
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=0, atol=tol["atol"] * scale)
+
+
+TGV = [
+    ("tgv2d_d2q9_bgk_32_f64", "D2Q9", "bgk", "f64", (10, 100)),
+    ("tgv2d_d2q9_bgk_32_f32", "D2Q9", "bgk", "f32", (10, 100)),
+    ("tgv2d_d2q9_kbc_32_f64", "D2Q9", "kbc", "f64", (10, 50)),
+    ("tgv3d_d3q19_bgk_16_f64", "D3Q19", "bgk", "f64", (10, 100)),
+    ("tgv3d_d3q19_bgk_16_f32", "D3Q19", "bgk", "f32", (10, 100)),
+    ("tgv3d_d3q19_bgk_ragged_f64", "D3Q19", "bgk", "f64", (7,)),
+    ("tgv3d_d3q27_bgk_16_f64", "D3Q27", "bgk", "f64", (10,)),
+    ("tgv3d_d3q27_kbc_16_f64", "D3Q27", "kbc", "f64", (10, 50)),
+    ("tgv3d_d3q27_kbc_16_f32", "D3Q27", "kbc", "f32", (10,)),
+]
+
+
+@pytest.mark.parametrize("name,lat,coll,dt,snaps", TGV, ids=[t[0] for t in TGV])
+def test_tgv_initial_condition_and_steps(name, lat, coll, dt, snaps):
+    g = golden(name)
+    res = [int(r) for r in g["resolution"]]
+    sim = orc.taylor_green(res, float(g["reynolds"]), float(g["mach"]), lat, TORCH_DT[dt], coll)
+    assert sim.tau == pytest.approx(float(g["tau"]), rel=1e-15)
+    close(sim.f.numpy(), g["f0"], dt)                      # F1: init incl. f_neq
+    energies = {0: float(orc.kinetic_energy_pu(sim.f, sim.lat, sim.units))}
+    for i in range(1, max(snaps) + 1):
+        sim.step()
+        if i in snaps:
+            close(sim.f.numpy(), g[f"f{i}"], dt, scale=max(1.0, i / 10))
+        if i in g["energy_steps"]:
+            energies[i] = float(orc.kinetic_energy_pu(sim.f, sim.lat, sim.units))
+    ref = dict(zip(g["energy_steps"].tolist(), g["energy_pu"].tolist()))
+    for i, e in energies.items():
+        assert e == pytest.approx(ref[i], rel=1e-12 if dt == "f64" else 2e-6)
+
+
+def test_cfg1_anchor_energies():
+    """SURVEY.md 8(c) anchors for examples/00_simplest_TGV.py (128^2 fp64)."""
+    g = golden("tgv2d_d2q9_bgk_128_f64")
+    assert float(g["tau"]) == pytest.approx(0.610851251684408, rel=1e-14)
+    assert g["energy_pu"][0] == pytest.approx(9.86960440108935, rel=1e-13)
+    assert g["energy_pu"][1] == pytest.approx(9.52452318761345, rel=1e-13)
+    sim = orc.taylor_green([128, 128], 100, 0.05, "D2Q9", torch.float64)
+    close(sim.f.numpy(), g["f0"], "f64")
+    sim.step(100)
+    close(sim.f.numpy(), g["f100"], "f64", scale=10)
+    assert float(orc.kinetic_energy_pu(sim.f, sim.lat, sim.units)) == pytest.approx(
+        float(g["energy_pu"][1]), rel=1e-12)
+
+
+OBST = [("obstacle2d_d2q9_bgk_f64", "D2Q9", "bgk", "f64", (1, 2, 10)),
+        ("obstacle3d_d3q27_kbc_f64", "D3Q27", "kbc", "f64", (1, 2, 8)),
+        ("obstacle3d_d3q27_kbc_f32", "D3Q27", "kbc", "f32", (2, 8)),
+        ("obstacle3d_d3q19_bgk_f64", "D3Q19", "bgk", "f64", (2, 8))]
+
+
+def obstacle_oracle(g, lat_name, coll, dt):
+    lat = orc.LATTICES[lat_name]
+    res = [int(r) for r in g["resolution"]]
+    units = orc.Units(100, 0.1, characteristic_length_lu=float(g["char_length_lu"]),
+                      characteristic_length_pu=1, characteristic_velocity_pu=1)
+    dtype = TORCH_DT[dt]
+    x = torch.meshgrid(*[units.length_to_pu(torch.arange(n)) for n in res], indexing="ij")[0]
+    direction = [1] + [0] * (lat.d - 1)
+    bnds = [
+        orc.OracleBoundary("equilibrium_pu", mask=torch.abs(x) < 1e-6,
+                           velocity_pu=torch.tensor([1.0] + [0.0] * (lat.d - 1), dtype=dtype),
+                           pressure_pu=torch.tensor(0, dtype=dtype)),
+        orc.OracleBoundary("abb_outlet", direction=direction),
+        orc.OracleBoundary("bounce_back", mask=torch.tensor(g["obstacle_mask"])),
+    ]
+    return orc.OracleSimulation(lat, torch.tensor(g["f0"]), coll, float(g["tau"]), units, bnds)
+
+
+@pytest.mark.parametrize("name,lat,coll,dt,snaps", OBST, ids=[t[0] for t in OBST])
+def test_obstacle_masks_and_steps(name, lat, coll, dt, snaps):
+    g = golden(name)
+    assert list(g["boundary_order"]) == ["AntiBounceBackOutlet", "BounceBackBoundary",
+                                         "EquilibriumBoundaryPU"]
+    sim = obstacle_oracle(g, lat, coll, dt)
+    assert sim.tau == pytest.approx(orc.Units(100, 0.1, float(g["char_length_lu"])).tau, rel=1e-15)
+    np.testing.assert_array_equal(sim.no_collision_mask.numpy(), g["no_collision_mask"])
+    np.testing.assert_array_equal(sim.no_streaming_mask.numpy(), unpack_nsm(g))
+    for i in range(1, max(snaps) + 1):
+        sim.step()
+        if i in snaps:
+            close(sim.f.numpy(), g[f"f{i}"], dt, scale=2)
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_shear3d_steps(dt):
+    g = golden(f"shear3d_d3q19_bgk_{dt}")
+    sim = orc.OracleSimulation(orc.LATTICES["D3Q19"], torch.tensor(g["f0"]), "bgk", float(g["tau"]))
+    sim.step(5)
+    close(sim.f.numpy(), g["f5"], dt)
+    sim.step(15)
+    close(sim.f.numpy(), g["f20"], dt, scale=4)
+
+
+def test_hand_set_streaming_bgk_bounce_back():
+    lat = orc.LATTICES["D2Q9"]
+    g = golden("native_streaming_d2q9_f32")
+    sim = orc.OracleSimulation(lat, torch.tensor(g["f0"]), "none", 1.0)
+    np.testing.assert_array_equal(sim.step().numpy(), g["f1"])      # pure data movement
+    g = golden("native_bgk_d2q9_f32")
+    sim = orc.OracleSimulation(lat, torch.tensor(g["f0"]), "bgk", float(g["tau"]))
+    close(sim.step().numpy(), g["f1"], "f32")
+    g = golden("native_bounce_back_d2q9_f32")
+    b = orc.OracleBoundary("bounce_back", mask=torch.tensor(g["no_collision_mask"]).bool())
+    sim = orc.OracleSimulation(lat, torch.tensor(g["f0"]), "none", 1.0, boundaries=[b])
+    np.testing.assert_array_equal(sim.step().numpy(), g["f1"])
+    np.testing.assert_array_equal(sim.step().numpy(), g["f2"])
+
+
+def test_hand_set_equilibrium_pu_and_no_streaming_mask():
+    lat = orc.LATTICES["D2Q9"]
+    g = golden("native_equilibrium_pu_d2q9_f64")
+    units = orc.tgv_units([16, 16], 1, 0.1)
+    assert units.u_char_lu == pytest.approx(float(g["u_char_lu"]), rel=1e-15)
+    mask = torch.zeros(16, 16, dtype=torch.bool)
+    mask[:, 1] = True
+    b = orc.OracleBoundary("equilibrium_pu", mask=mask,
+                           velocity_pu=torch.ones(2, 16, 16, dtype=torch.float64),
+                           pressure_pu=torch.ones(16, 16, dtype=torch.float64),
+                           no_streaming_mask=torch.ones(9, 16, 16, dtype=torch.bool))
+    sim = orc.OracleSimulation(lat, torch.tensor(g["f0"]), "none", 1.0, units, [b])
+    close(sim.step().numpy(), g["f1"], "f64")
+    # a grid-shaped (not [q,*res]) all-zero mask assigned after construction
+    g = golden("native_no_streaming_mask_d2q9_f32")
+    sim = orc.OracleSimulation(lat, torch.tensor(g["f0"]), "none", 1.0)
+    sim.no_streaming_mask = torch.zeros(16, 16, dtype=torch.bool)
+    close(sim.step(64).numpy(), g["f64"], "f32")
+
+
+OPS = [(s, d) for s in ("d2q9", "d3q19", "d3q27") for d in ("f64", "f32")]
+
+
+@pytest.mark.parametrize("sname,dt", OPS, ids=[f"{s}-{d}" for s, d in OPS])
+def test_whole_field_operators(sname, dt):
+    g = golden(f"operators_{sname}_{dt}")
+    lat = orc.LATTICES[sname.upper()]
+    f = torch.tensor(g["f"])
+    e, w = orc.lattice_tensors(lat, f.dtype)
+    close(orc.density(f).numpy(), g["rho"], dt)
+    close(orc.momentum(f, e).numpy(), g["j"], dt)
+    close(orc.velocity(f, e).numpy(), g["u"], dt)
+    close(orc.incompressible_energy(f, e).numpy(), g["energy"], dt)
+    close(orc.quadratic_equilibrium(orc.density(f), orc.velocity(f, e), e, w).numpy(), g["feq"], dt)
+    close(orc.bgk(f, float(g["tau"]), e, w).numpy(), g["bgk"], dt)
+    np.testing.assert_array_equal(orc.bounce_back(f, lat).numpy(), g["bounce_back"])
+    if "kbc" in g:
+        close(orc.kbc(f, float(g["tau_units"]), e, w).numpy(), g["kbc"], dt, scale=4)
+    for axis in range(lat.d):
+        for sign, tag in ((1, "p"), (-1, "m")):
+            direction = [0] * lat.d
+            direction[axis] = sign
+            b = orc.OracleBoundary("abb_outlet", direction=direction)
+            key = f"abb_{'xyz'[axis]}{tag}"
+            close(orc.abb_outlet_inplace(f.clone(), b, lat, e, w).numpy(), g[key], dt)
+            ncm, nsm = orc.abb_masks(f.shape, b, lat)
+            np.testing.assert_array_equal(ncm.numpy(), g[key + "_ncm"])
+            np.testing.assert_array_equal(nsm.numpy(), g[key + "_nsm"])
