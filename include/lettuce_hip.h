@@ -1,0 +1,187 @@
+/* lettuce_hip.h -- C ABI of the MI355X (gfx950) lattice-Boltzmann stream-and-collide engine.
+ *
+ * This is the drop-in boundary of the build: a plain-C shared library
+ * (liblettuce_hip.so) with raw device pointers and sizes, no torch types.  It
+ * takes the place of the module the reference JIT-generates and binds with
+ * pybind11 for the same slot:
+ *
+ *   reference entry point  void collide_and_stream_<hash>(at::Tensor f, at::Tensor f_next
+ *                              [, at::Tensor no_collision_mask, at::Tensor no_streaming_mask]
+ *                              [, double tau_inv] [, at::Tensor velocityN, at::Tensor densityN ...])
+ *                          lettuce/cuda_native/_template.py:58-86 (binding), :297-367 (launcher),
+ *                          :175-295 (kernel), :31-44 (python invoke, f/f_next swap)
+ *   reference swap point   Simulation._collide_and_stream, lettuce/_simulation.py:92-96,148,202
+ *
+ * All pointers named *_dev are device pointers (tensor.data_ptr()); buffers are
+ * owned by the caller (lettuce/_flow.py:90,124-134) and only borrowed for the
+ * call.  Engine-owned scratch (compressed masks, boundary tables, reduction
+ * partials) lives in the plan and is released by lt_plan_destroy.  Every launch
+ * goes to the caller's HIP stream and returns without synchronising.
+ *
+ * Memory layout of a population field ("f"): [q][a2][a1][a0], a0 fastest.
+ *   LT_LAYOUT_REFERENCE  a0 = last logical axis: f[q][x][y][z] (3-D), f[q][x][y] (2-D)
+ *                        -- exactly the reference's C-contiguous tensor (lettuce/_flow.py:90).
+ *   LT_LAYOUT_SLAB       3-D only, a0 = x, a2 = z: f[q][z][y][x]; used by the multi-GPU
+ *                        z-slab driver so that ghost planes are contiguous.
+ * ghost_planes = 1 adds one plane below and one above along a2 (slab exchange);
+ * then a2 has shape_a2 + 2 planes and no periodic wrap is applied along it.
+ *
+ * Error convention: every function returns LT_OK (0) or a positive LT_ERR_* code
+ * and never aborts; lt_last_error() gives the message of the calling thread's
+ * last failure (the reference asserts / TORCH_CHECKs: _template.py:53-56,317-323).
+ */
+#ifndef LETTUCE_HIP_H
+#define LETTUCE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LT_ABI_VERSION 1
+#define LT_MAX_BOUNDARIES 7
+#define LT_MAX_Q 27
+
+enum lt_status {
+  LT_OK = 0,
+  LT_ERR_INVALID = 1,      /* bad argument (null pointer, shape, alignment, in == out ...) */
+  LT_ERR_UNSUPPORTED = 2,  /* valid request the engine has no kernel for */
+  LT_ERR_HIP = 3,          /* a HIP runtime call failed */
+  LT_ERR_ALLOC = 4
+};
+
+/* lettuce/ext/_stencil/d2q9.py:8-10, d3q19.py:8-13, d3q27.py:8-12 (same velocity order) */
+enum lt_stencil { LT_D2Q9 = 0, LT_D3Q19 = 1, LT_D3Q27 = 2 };
+/* AT_DISPATCH_FLOATING_TYPES, lettuce/cuda_native/_template.py:357 */
+enum lt_dtype { LT_F32 = 0, LT_F64 = 1 };
+/* lettuce/ext/_collision/no_collision.py:9-17, bgk_collision.py:12-35, kbc_collision.py:11-166 */
+enum lt_collision { LT_COLLISION_NONE = 0, LT_COLLISION_BGK = 1, LT_COLLISION_KBC = 2 };
+/* lettuce/ext/_boundary/bounce_back_boundary.py:10-32, equilibrium_boundary_pu.py:13-46,
+ * anti_bounce_back_outlet.py:13-109 */
+enum lt_boundary_kind {
+  LT_BOUNDARY_BOUNCE_BACK = 1,
+  LT_BOUNDARY_EQUILIBRIUM = 2,
+  LT_BOUNDARY_ABB_OUTLET = 3
+};
+enum lt_layout { LT_LAYOUT_REFERENCE = 0, LT_LAYOUT_SLAB = 1 };
+
+/* One entry of Simulation.boundaries[1:] (lettuce/_simulation.py:57-58); entry i (0-based)
+ * is the boundary whose index in no_collision_mask is i + 1. */
+typedef struct lt_boundary_desc {
+  int32_t kind;            /* lt_boundary_kind */
+  int32_t axis;            /* ABB outlet: logical axis of `direction` (0 = x) */
+  int32_t side;            /* ABB outlet: +1 or -1 */
+  int32_t reserved;
+  /* EQUILIBRIUM with uniform velocity/pressure: the populations written on the masked
+   * nodes, i.e. feq(rho(p_pu), u_lu(v_pu)) as the host evaluated it in the flow's dtype. */
+  double feq[LT_MAX_Q];
+  /* EQUILIBRIUM with per-node velocity/pressure: device pointer to a [q, *res] field of the
+   * plan's dtype (borrowed; must outlive the plan or be re-set), or NULL. */
+  const void *feq_field_dev;
+} lt_boundary_desc;
+
+typedef struct lt_plan_desc {
+  int32_t abi_version;     /* LT_ABI_VERSION */
+  int32_t stencil;         /* lt_stencil */
+  int32_t dtype;           /* lt_dtype */
+  int32_t collision;       /* lt_collision */
+  int32_t layout;          /* lt_layout */
+  int32_t ghost_planes;    /* 0, or 1 (LT_LAYOUT_SLAB only) */
+  int32_t dims;            /* 2 or 3; must match the stencil */
+  int32_t n_boundaries;    /* 0 .. LT_MAX_BOUNDARIES */
+  int64_t shape[3];        /* logical resolution (nx, ny, nz); nz = 1 in 2-D.  With ghost
+                              planes this is the rank-local slab WITHOUT the ghosts. */
+  lt_boundary_desc boundaries[LT_MAX_BOUNDARIES];
+} lt_plan_desc;
+
+typedef struct lt_plan lt_plan;
+
+int lt_abi_version(void);
+const char *lt_last_error(void);
+
+int lt_plan_create(const lt_plan_desc *desc, lt_plan **out_plan);
+int lt_plan_destroy(lt_plan *plan);
+
+/* Compile Simulation.no_collision_mask (uint8 [*res], value = boundary index,
+ * lettuce/_simulation.py:73-82) and Simulation.no_streaming_mask (uint8 [q, *res], 0/1,
+ * :83-86; may be NULL) into the plan's node-descriptor byte (+ a sparse per-node bit set for
+ * the streaming mask).  Both NULL removes the masks.  Required before stepping a plan that
+ * has boundaries. */
+int lt_plan_set_masks(lt_plan *plan, const uint8_t *no_collision_mask_dev,
+                      const uint8_t *no_streaming_mask_dev, void *stream);
+
+/* Replace boundary i's parameters (e.g. inlet velocity changed between calls; the reference
+ * re-reads them every step, cuda_native/ext/_boundary/equilibrium_pu.py:40-48). */
+int lt_plan_update_boundary(lt_plan *plan, int32_t index, const lt_boundary_desc *desc,
+                            void *stream);
+
+/* out = B(C(in)): collision on nodes with no_collision_mask == 0, then the boundaries in
+ * index order; no streaming (Simulation._collide, lettuce/_simulation.py:177-189).
+ * in != out. */
+int lt_collide(lt_plan *plan, const void *f_dev, void *f_out_dev, double tau, void *stream);
+
+/* out = S(in): periodic streaming, destination-side no-streaming mask
+ * (Simulation._stream, lettuce/_simulation.py:160-175).  in != out. */
+int lt_stream(lt_plan *plan, const void *f_dev, void *f_out_dev, void *stream);
+
+/* out = B(C(S(in))): the fused pull-scheme kernel.  `in` and `out` hold post-collision
+ * populations ("f*").  in != out. */
+int lt_stream_collide(lt_plan *plan, const void *fstar_dev, void *fstar_out_dev, double tau,
+                      void *stream);
+
+/* Same three operators restricted to memory planes [plane_begin, plane_end) of the slowest
+ * axis a2 (ghost-plane numbering: 0 is the lower ghost).  Used by the slab driver to do the
+ * two boundary planes first and the interior while the halo exchange is in flight. */
+int lt_collide_planes(lt_plan *plan, const void *f_dev, void *f_out_dev, double tau,
+                      int64_t plane_begin, int64_t plane_end, void *stream);
+int lt_stream_planes(lt_plan *plan, const void *f_dev, void *f_out_dev,
+                     int64_t plane_begin, int64_t plane_end, void *stream);
+int lt_stream_collide_planes(lt_plan *plan, const void *fstar_dev, void *fstar_out_dev,
+                             double tau, int64_t plane_begin, int64_t plane_end, void *stream);
+
+/* n whole lettuce steps (collide, boundaries, stream) starting from post-streaming
+ * populations in buf_a (lettuce/_simulation.py:201-203): one collide launch, n-1 fused
+ * launches, one stream launch, ping-ponging between the two buffers.  On return
+ * *result_in_b tells which buffer holds the new post-streaming populations (1 = buf_b);
+ * the other buffer then holds the post-collision populations of the last step, from which
+ * lt_continue can carry on without the extra collide pass. */
+int lt_run(lt_plan *plan, void *buf_a_dev, void *buf_b_dev, double tau, int64_t n_steps,
+           void *stream, int32_t *result_in_b);
+/* As lt_run, but buf_a holds post-collision populations f* of the step before (what lt_run
+ * leaves in the non-result buffer): n fused launches + one stream launch. */
+int lt_continue(lt_plan *plan, void *fstar_a_dev, void *buf_b_dev, double tau, int64_t n_steps,
+                void *stream, int32_t *result_in_b);
+
+/* rho [*res] and u [d, *res] (either may be NULL) from post-streaming populations
+ * (Flow.rho / Flow.j / Flow.u, lettuce/_flow.py:136-138,152-172). */
+int lt_macroscopic(lt_plan *plan, const void *f_dev, void *rho_dev, void *u_dev, void *stream);
+
+/* feq [q, *res] from rho [*res] and u [d, *res]
+ * (QuadraticEquilibrium.__call__, lettuce/ext/_equilibrium/quadratic_equilibrium.py:11-25). */
+int lt_equilibrium(lt_plan *plan, const void *rho_dev, const void *u_dev, void *feq_dev,
+                   void *stream);
+
+/* *out_dev (one double, device memory) = sum over nodes of 0.5 * u.u in lattice units,
+ * accumulated in fp64 with a fixed reduction order (Flow.incompressible_energy summed as in
+ * IncompressibleKineticEnergy, lettuce/_flow.py:178-181,
+ * lettuce/ext/_reporter/observable_reporter.py:34-42; the pu scaling stays on the host).
+ * Ghost planes are excluded. */
+int lt_kinetic_energy(lt_plan *plan, const void *f_dev, double *out_dev, void *stream);
+
+/* *out_dev = sum over nodes and populations of f (total mass, fp64 accumulation). */
+int lt_mass(lt_plan *plan, const void *f_dev, double *out_dev, void *stream);
+
+/* Introspection for tests and benchmarks. */
+int lt_plan_kernel_info(lt_plan *plan, int32_t *vec_width, int32_t *threads_per_block,
+                        int64_t *blocks_per_launch);
+/* Name of the fused kernel variant this plan launches (for matching rocprof rows). */
+const char *lt_plan_kernel_name(lt_plan *plan);
+/* Tuning knob for experiments: 0 = aligned vector load + one neighbour element,
+ * 1 = unaligned vector load, 2 = aligned vector load + cross-lane shift. */
+int lt_plan_set_shift_policy(lt_plan *plan, int32_t policy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LETTUCE_HIP_H */

@@ -1,0 +1,333 @@
+"""ctypes binding of the C-ABI HIP engine (include/lettuce_hip.h).
+
+This is the host side of the drop-in boundary: it plays the role of the
+reference's generated python ``invoke`` + pybind module
+(lettuce/cuda_native/_template.py:31-44,58-86) but binds a prebuilt shared
+library instead of JIT-compiling one per configuration.  PyTorch tensors are
+only containers here: the engine sees ``tensor.data_ptr()`` and the raw
+``hipStream_t`` of torch's current stream.
+
+There is no CPU fallback in this module: if the library is missing or a
+combination is unsupported, a ``LettuceException`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence
+
+import torch
+
+__all__ = ["NativeEngineError", "load_library", "library_path", "Plan", "STENCIL_IDS",
+           "COLLISION_IDS", "BOUNDARY_KINDS"]
+
+LT_ABI_VERSION = 1
+LT_MAX_BOUNDARIES = 7
+LT_MAX_Q = 27
+
+STENCIL_IDS = {"D2Q9": 0, "D3Q19": 1, "D3Q27": 2}
+DTYPE_IDS = {torch.float32: 0, torch.float64: 1}
+COLLISION_IDS = {"none": 0, "bgk": 1, "kbc": 2}
+BOUNDARY_KINDS = {"bounce_back": 1, "equilibrium": 2, "abb_outlet": 3}
+LAYOUT_REFERENCE, LAYOUT_SLAB = 0, 1
+
+
+class NativeEngineError(Exception):
+    """Raised for every failure of the HIP engine (library missing, unsupported
+    configuration, HIP error).  ``lettuce_amd.LettuceException`` derives from the same base
+    the reference uses (lettuce/util/utility.py:21-22); this subclass is re-exported there."""
+
+
+class _BoundaryDesc(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("axis", ctypes.c_int32), ("side", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("feq", ctypes.c_double * LT_MAX_Q),
+                ("feq_field_dev", ctypes.c_void_p)]
+
+
+class _PlanDesc(ctypes.Structure):
+    _fields_ = [("abi_version", ctypes.c_int32), ("stencil", ctypes.c_int32),
+                ("dtype", ctypes.c_int32), ("collision", ctypes.c_int32),
+                ("layout", ctypes.c_int32), ("ghost_planes", ctypes.c_int32),
+                ("dims", ctypes.c_int32), ("n_boundaries", ctypes.c_int32),
+                ("shape", ctypes.c_int64 * 3),
+                ("boundaries", _BoundaryDesc * LT_MAX_BOUNDARIES)]
+
+
+# every symbol include/lettuce_hip.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+SYMBOLS = {
+    "lt_abi_version": (ctypes.c_int, []),
+    "lt_last_error": (ctypes.c_char_p, []),
+    "lt_plan_create": (ctypes.c_int, [ctypes.POINTER(_PlanDesc), ctypes.POINTER(_vp)]),
+    "lt_plan_destroy": (ctypes.c_int, [_vp]),
+    "lt_plan_set_masks": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "lt_plan_update_boundary": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_BoundaryDesc), _vp]),
+    "lt_collide": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _vp]),
+    "lt_stream": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "lt_stream_collide": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _vp]),
+    "lt_collide_planes": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _i64, _i64, _vp]),
+    "lt_stream_planes": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "lt_stream_collide_planes": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _i64, _i64, _vp]),
+    "lt_run": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _i64, _vp, ctypes.POINTER(_i32)]),
+    "lt_continue": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _i64, _vp, ctypes.POINTER(_i32)]),
+    "lt_macroscopic": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "lt_equilibrium": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "lt_kinetic_energy": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "lt_mass": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "lt_plan_kernel_info": (ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i32),
+                                           ctypes.POINTER(_i64)]),
+    "lt_plan_kernel_name": (ctypes.c_char_p, [_vp]),
+    "lt_plan_set_shift_policy": (ctypes.c_int, [_vp, _i32]),
+}
+
+_LIB = None
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblettuce_hip.so")
+
+
+def load_library() -> ctypes.CDLL:
+    """Load liblettuce_hip.so (built in-tree by ``__graft_entry__.build()`` /
+    ``make -C lettuce_amd/csrc``) and bind every declared symbol."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise NativeEngineError(
+            f"HIP engine library not found at {path}; build it with "
+            f"`make -C lettuce_amd/csrc -j8` or `python -c 'import __graft_entry__ as g; g.build()'`")
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as exc:
+        raise NativeEngineError(f"cannot load {path}: {exc}") from exc
+    for name, (restype, argtypes) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise NativeEngineError(f"{path} does not export {name}") from exc
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.lt_abi_version() != LT_ABI_VERSION:
+        raise NativeEngineError(f"ABI mismatch: library {lib.lt_abi_version()}, "
+                                f"binding {LT_ABI_VERSION}")
+    _LIB = lib
+    return lib
+
+
+def _stream_handle() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class Plan:
+    """One engine configuration: lattice x dtype x collision x grid (x boundaries).
+
+    ``boundaries`` is a list of dicts in index order (index = position + 1 in
+    ``no_collision_mask``): ``{"kind": "bounce_back"}``,
+    ``{"kind": "equilibrium", "feq": [q floats] | "field": tensor[q,*res]}``,
+    ``{"kind": "abb_outlet", "axis": a, "side": +-1}``.
+    """
+
+    def __init__(self, stencil: str, dtype: torch.dtype, collision: str,
+                 resolution: Sequence[int], boundaries: Sequence[dict] = (),
+                 layout: int = LAYOUT_REFERENCE, ghost_planes: int = 0,
+                 device: Optional[torch.device] = None):
+        self._handle = None
+        self.lib = load_library()
+        if stencil not in STENCIL_IDS:
+            raise NativeEngineError(f"stencil {stencil} has no HIP kernels "
+                                    f"(available: {sorted(STENCIL_IDS)})")
+        if dtype not in DTYPE_IDS:
+            raise NativeEngineError(f"dtype {dtype} has no HIP kernels (float32/float64 only)")
+        if collision not in COLLISION_IDS:
+            raise NativeEngineError(f"collision {collision!r} has no HIP kernels")
+        if len(boundaries) > LT_MAX_BOUNDARIES:
+            raise NativeEngineError(f"{len(boundaries)} boundaries; the engine takes "
+                                    f"{LT_MAX_BOUNDARIES}")
+        self.stencil, self.dtype, self.collision = stencil, dtype, collision
+        self.resolution = [int(r) for r in resolution]
+        self.q = int(stencil.split("Q")[1])
+        self.d = len(self.resolution)
+        self.layout, self.ghost_planes = layout, ghost_planes
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._keepalive = []
+        desc = _PlanDesc()
+        desc.abi_version = LT_ABI_VERSION
+        desc.stencil = STENCIL_IDS[stencil]
+        desc.dtype = DTYPE_IDS[dtype]
+        desc.collision = COLLISION_IDS[collision]
+        desc.layout = layout
+        desc.ghost_planes = ghost_planes
+        desc.dims = self.d
+        desc.n_boundaries = len(boundaries)
+        for a in range(3):
+            desc.shape[a] = self.resolution[a] if a < self.d else 1
+        for i, b in enumerate(boundaries):
+            self._fill_boundary(desc.boundaries[i], b)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.lt_plan_create(ctypes.byref(desc), ctypes.byref(handle)))
+        self._handle = handle
+        self.n_boundaries = len(boundaries)
+
+    # ------------------------------------------------------------------ helpers
+    def _fill_boundary(self, out: _BoundaryDesc, b: dict):
+        out.kind = BOUNDARY_KINDS[b["kind"]]
+        out.axis = int(b.get("axis", 0))
+        out.side = int(b.get("side", 0))
+        out.feq_field_dev = None
+        if b["kind"] == "equilibrium":
+            field = b.get("field")
+            if field is not None:
+                field = field.to(device=self.device, dtype=self.dtype).contiguous()
+                self._keepalive.append(field)
+                out.feq_field_dev = field.data_ptr()
+            else:
+                for q, v in enumerate(b["feq"]):
+                    out.feq[q] = float(v)
+
+    def _check(self, code: int):
+        if code != 0:
+            msg = self.lib.lt_last_error().decode("utf-8", "replace")
+            raise NativeEngineError(f"HIP engine error {code}: {msg}")
+
+    def _tensor_ok(self, t: torch.Tensor, shape=None):
+        if t.device.type != "cuda":
+            raise NativeEngineError(f"tensor on {t.device}; the HIP engine needs device memory")
+        if t.dtype != self.dtype:
+            raise NativeEngineError(f"tensor dtype {t.dtype}, plan dtype {self.dtype}")
+        if not t.is_contiguous():
+            raise NativeEngineError("population tensors must be contiguous")
+        if shape is not None and list(t.shape) != list(shape):
+            raise NativeEngineError(f"tensor shape {list(t.shape)}, expected {list(shape)}")
+
+    @property
+    def f_shape(self):
+        """Shape of a population tensor in this plan's memory layout."""
+        if self.layout == LAYOUT_REFERENCE:
+            return [self.q] + self.resolution
+        nx, ny, nz = self.resolution
+        return [self.q, nz + 2 * self.ghost_planes, ny, nx]
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None:
+            self.lib.lt_plan_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ masks
+    def set_masks(self, no_collision_mask: Optional[torch.Tensor],
+                  no_streaming_mask: Optional[torch.Tensor]):
+        """uint8 ``[*res]`` / uint8 ``[q, *res]`` device tensors (either may be None)."""
+        ncm = nsm = None
+        if no_collision_mask is not None:
+            ncm = no_collision_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            if list(ncm.shape) != self.resolution:
+                raise NativeEngineError(f"no_collision_mask shape {list(ncm.shape)}")
+        if no_streaming_mask is not None:
+            nsm = no_streaming_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            if list(nsm.shape) != [self.q] + self.resolution:
+                raise NativeEngineError(f"no_streaming_mask shape {list(nsm.shape)}")
+        self._check(self.lib.lt_plan_set_masks(self._handle, _ptr(ncm), _ptr(nsm), _stream_handle()))
+        # the compile kernel reads them asynchronously on the current stream
+        if ncm is not None:
+            ncm.record_stream(torch.cuda.current_stream())
+        if nsm is not None:
+            nsm.record_stream(torch.cuda.current_stream())
+
+    def update_boundary(self, index: int, b: dict):
+        d = _BoundaryDesc()
+        self._fill_boundary(d, b)
+        self._check(self.lib.lt_plan_update_boundary(self._handle, index, ctypes.byref(d),
+                                                     _stream_handle()))
+
+    # ------------------------------------------------------------------ operators
+    def collide(self, f, out, tau):
+        self._tensor_ok(f, self.f_shape); self._tensor_ok(out, self.f_shape)
+        self._check(self.lib.lt_collide(self._handle, _ptr(f), _ptr(out), float(tau), _stream_handle()))
+        return out
+
+    def stream(self, f, out):
+        self._tensor_ok(f, self.f_shape); self._tensor_ok(out, self.f_shape)
+        self._check(self.lib.lt_stream(self._handle, _ptr(f), _ptr(out), _stream_handle()))
+        return out
+
+    def stream_collide(self, f, out, tau):
+        self._tensor_ok(f, self.f_shape); self._tensor_ok(out, self.f_shape)
+        self._check(self.lib.lt_stream_collide(self._handle, _ptr(f), _ptr(out), float(tau),
+                                               _stream_handle()))
+        return out
+
+    def collide_planes(self, f, out, tau, begin, end):
+        self._check(self.lib.lt_collide_planes(self._handle, _ptr(f), _ptr(out), float(tau),
+                                               int(begin), int(end), _stream_handle()))
+
+    def stream_planes(self, f, out, begin, end):
+        self._check(self.lib.lt_stream_planes(self._handle, _ptr(f), _ptr(out), int(begin),
+                                              int(end), _stream_handle()))
+
+    def stream_collide_planes(self, f, out, tau, begin, end):
+        self._check(self.lib.lt_stream_collide_planes(self._handle, _ptr(f), _ptr(out), float(tau),
+                                                      int(begin), int(end), _stream_handle()))
+
+    def run(self, a, b, tau, n_steps, from_fstar=False):
+        """n whole steps; returns (result, other): ``result`` holds the new post-streaming
+        populations, ``other`` the post-collision populations of the last step."""
+        self._tensor_ok(a, self.f_shape); self._tensor_ok(b, self.f_shape)
+        which = ctypes.c_int32(0)
+        fn = self.lib.lt_continue if from_fstar else self.lib.lt_run
+        self._check(fn(self._handle, _ptr(a), _ptr(b), float(tau), int(n_steps), _stream_handle(),
+                       ctypes.byref(which)))
+        return (b, a) if which.value else (a, b)
+
+    def macroscopic(self, f, want_rho=True, want_u=True):
+        self._tensor_ok(f, self.f_shape)
+        grid = self.f_shape[1:]
+        rho = torch.empty(grid, dtype=self.dtype, device=f.device) if want_rho else None
+        u = torch.empty([self.d] + grid, dtype=self.dtype, device=f.device) if want_u else None
+        self._check(self.lib.lt_macroscopic(self._handle, _ptr(f), _ptr(rho), _ptr(u), _stream_handle()))
+        return rho, u
+
+    def equilibrium(self, rho, u):
+        grid = self.f_shape[1:]
+        rho = rho.reshape(grid).contiguous()
+        self._tensor_ok(rho, grid); self._tensor_ok(u, [self.d] + grid)
+        feq = torch.empty(self.f_shape, dtype=self.dtype, device=rho.device)
+        self._check(self.lib.lt_equilibrium(self._handle, _ptr(rho), _ptr(u), _ptr(feq), _stream_handle()))
+        return feq
+
+    def kinetic_energy_lu(self, f):
+        """0-d float64 device tensor: sum over nodes of 0.5 u.u (lattice units)."""
+        self._tensor_ok(f, self.f_shape)
+        out = torch.empty((), dtype=torch.float64, device=f.device)
+        self._check(self.lib.lt_kinetic_energy(self._handle, _ptr(f), _ptr(out), _stream_handle()))
+        return out
+
+    def mass(self, f):
+        self._tensor_ok(f, self.f_shape)
+        out = torch.empty((), dtype=torch.float64, device=f.device)
+        self._check(self.lib.lt_mass(self._handle, _ptr(f), _ptr(out), _stream_handle()))
+        return out
+
+    # ------------------------------------------------------------------ introspection
+    def kernel_info(self):
+        vec, tpb, blocks = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+        self._check(self.lib.lt_plan_kernel_info(self._handle, ctypes.byref(vec), ctypes.byref(tpb),
+                                                 ctypes.byref(blocks)))
+        return {"vec": vec.value, "threads_per_block": tpb.value, "blocks": blocks.value}
+
+    def kernel_name(self) -> str:
+        return self.lib.lt_plan_kernel_name(self._handle).decode()
+
+    def set_shift_policy(self, policy: int):
+        self._check(self.lib.lt_plan_set_shift_policy(self._handle, int(policy)))

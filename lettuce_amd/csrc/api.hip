@@ -1,0 +1,394 @@
+// C ABI of the engine (include/lettuce_hip.h): plan handling, argument checks, dispatch to
+// the per-(stencil, dtype) kernel units.  No kernel code here.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "dispatch.hpp"
+#include "kernels.hpp"
+#include "lettuce_hip.h"
+
+namespace {
+
+thread_local char g_error[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof g_error, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define LT_HIP(call)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail(LT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));          \
+  } while (0)
+
+struct Unit {
+  lt::StepFn step;
+  lt::AuxFn aux;
+  lt::NameFn name;
+  int q, d;
+};
+
+const Unit kUnits[3][2] = {
+    {{lt::step_d2q9_f32, lt::aux_d2q9_f32, lt::name_d2q9_f32, 9, 2},
+     {lt::step_d2q9_f64, lt::aux_d2q9_f64, lt::name_d2q9_f64, 9, 2}},
+    {{lt::step_d3q19_f32, lt::aux_d3q19_f32, lt::name_d3q19_f32, 19, 3},
+     {lt::step_d3q19_f64, lt::aux_d3q19_f64, lt::name_d3q19_f64, 19, 3}},
+    {{lt::step_d3q27_f32, lt::aux_d3q27_f32, lt::name_d3q27_f32, 27, 3},
+     {lt::step_d3q27_f64, lt::aux_d3q27_f64, lt::name_d3q27_f64, 27, 3}},
+};
+
+constexpr int kReduceBlocks = 1024;
+
+}  // namespace
+
+struct lt_plan {
+  lt_plan_desc desc;
+  Unit unit;
+  int esize;                 // sizeof scalar
+  int n0, n1, n2;            // memory extents incl. ghost planes
+  int interior_begin, interior_end;   // a2 planes that are real nodes
+  long long N;               // n0*n1*n2
+  int wide_ok;               // n0 divisible by the 16-byte vector width
+  int shift;
+  // engine-owned device scratch
+  unsigned char *node = nullptr;
+  unsigned *nsm_bits = nullptr;
+  void *bt = nullptr;        // BoundaryTable<T>
+  double *partial = nullptr;
+  int masked = 0;
+  char kernel_name[192];
+};
+
+namespace {
+
+int mem_axis_of(const lt_plan *p, int logical_axis) {
+  if (p->unit.d == 2) return logical_axis == 0 ? 1 : 0;
+  return p->desc.layout == LT_LAYOUT_REFERENCE ? 2 - logical_axis : logical_axis;
+}
+
+template <typename T>
+int upload_boundaries(lt_plan *p, hipStream_t stream) {
+  lt::BoundaryTable<T> h;
+  memset(&h, 0, sizeof h);
+  const int ext[3] = {p->n0, p->n1, p->n2};
+  for (int i = 0; i < p->desc.n_boundaries; ++i) {
+    const lt_boundary_desc &b = p->desc.boundaries[i];
+    const int s = i + 1;
+    h.kind[s] = b.kind;
+    if (b.kind == LT_BOUNDARY_ABB_OUTLET) {
+      const int ax = mem_axis_of(p, b.axis);
+      h.mem_axis[s] = ax;
+      h.side[s] = b.side;
+      h.plane[s] = b.side > 0 ? ext[ax] - 1 : 0;
+      h.nbr[s] = b.side > 0 ? ext[ax] - 2 : 1;
+    } else if (b.kind == LT_BOUNDARY_EQUILIBRIUM) {
+      for (int q = 0; q < p->unit.q; ++q) h.feq[s][q] = (T)b.feq[q];
+      h.field[s] = static_cast<const T *>(b.feq_field_dev);
+    }
+  }
+  // staged through the (pageable) host struct: synchronous w.r.t. the host, ordered on stream
+  LT_HIP(hipMemcpyAsync(p->bt, &h, sizeof h, hipMemcpyHostToDevice, stream));
+  LT_HIP(hipStreamSynchronize(stream));
+  return LT_OK;
+}
+
+int check_boundary(const lt_plan *p, const lt_boundary_desc &b, int n_abb_before) {
+  switch (b.kind) {
+    case LT_BOUNDARY_BOUNCE_BACK:
+    case LT_BOUNDARY_EQUILIBRIUM:
+      return LT_OK;
+    case LT_BOUNDARY_ABB_OUTLET: {
+      if (b.axis < 0 || b.axis >= p->unit.d || (b.side != 1 && b.side != -1))
+        return fail(LT_ERR_INVALID, "anti-bounce-back outlet: axis %d side %d", b.axis, b.side);
+      if (p->desc.shape[b.axis] < 2)
+        return fail(LT_ERR_INVALID, "anti-bounce-back outlet needs >= 2 planes along its axis");
+      if (n_abb_before > 0)
+        return fail(LT_ERR_UNSUPPORTED,
+                    "more than one AntiBounceBackOutlet per flow is not supported by the HIP engine");
+      return LT_OK;
+    }
+    default:
+      return fail(LT_ERR_INVALID, "unknown boundary kind %d", b.kind);
+  }
+}
+
+int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long pb, long long pe,
+         void *stream) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (!in || !out) return fail(LT_ERR_INVALID, "null population buffer");
+  if (in == out) return fail(LT_ERR_INVALID, "in-place operation is not supported (in == out)");
+  if (pb < 0 || pe > p->n2 || pb > pe)
+    return fail(LT_ERR_INVALID, "plane range [%lld, %lld) outside [0, %d)", pb, pe, p->n2);
+  if (p->desc.ghost_planes && (pb < 1 || pe > p->n2 - 1) && mode != lt::kCollideOnly && pe > pb)
+    return fail(LT_ERR_INVALID, "streaming from ghost planes: range [%lld, %lld) must stay in [1, %d)",
+                pb, pe, p->n2 - 1);
+  if (p->desc.n_boundaries > 0 && !p->masked)
+    return fail(LT_ERR_INVALID, "plan has boundaries but lt_plan_set_masks was not called");
+  if (mode != lt::kStreamOnly && p->desc.collision != LT_COLLISION_NONE && !(tau > 0.0))
+    return fail(LT_ERR_INVALID, "relaxation time tau = %g", tau);
+  lt::StepArgs a;
+  memset(&a, 0, sizeof a);
+  a.in = in; a.out = out;
+  a.n0 = p->n0; a.n1 = p->n1; a.n2 = p->n2;
+  a.p_begin = (int)pb; a.planes = (int)(pe - pb);
+  a.wrap2 = p->desc.ghost_planes ? 0 : 1;
+  a.tau = tau > 0.0 ? tau : 1.0;
+  a.node = p->node; a.nsm_bits = p->nsm_bits; a.bt = p->bt; a.nb = p->desc.n_boundaries;
+  a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = mode;
+  a.masked = p->masked;
+  const bool aligned = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  a.wide = (p->wide_ok && aligned) ? 1 : 0;
+  a.shift = (a.wide && mode == lt::kFused && !a.masked && a.coll == LT_COLLISION_BGK) ? p->shift : 0;
+  a.stream = static_cast<hipStream_t>(stream);
+  const int r = p->unit.step(a);
+  if (r == lt::kNoKernel)
+    return fail(LT_ERR_UNSUPPORTED, "no kernel for layout %d collision %d mode %d masked %d",
+                a.layout, a.coll, a.mode, a.masked);
+  if (r != 0) return fail(LT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)r));
+  return LT_OK;
+}
+
+int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, void *stream,
+        int32_t *result_in_b) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (n < 1) return fail(LT_ERR_INVALID, "n_steps = %lld", n);
+  if (!result_in_b) return fail(LT_ERR_INVALID, "null result_in_b");
+  if (p->desc.ghost_planes)
+    return fail(LT_ERR_UNSUPPORTED, "lt_run/lt_continue need a periodic plan (no ghost planes); "
+                                    "drive slabs with the *_planes entry points");
+  void *cur = a, *other = b;
+  int rc;
+  long long fused = n;
+  if (!from_fstar) {
+    rc = step(p, lt::kCollideOnly, cur, other, tau, 0, p->n2, stream);
+    if (rc) return rc;
+    void *t = cur; cur = other; other = t;
+    fused = n - 1;
+  }
+  for (long long i = 0; i < fused; ++i) {
+    rc = step(p, lt::kFused, cur, other, tau, 0, p->n2, stream);
+    if (rc) return rc;
+    void *t = cur; cur = other; other = t;
+  }
+  rc = step(p, lt::kStreamOnly, cur, other, tau, 0, p->n2, stream);
+  if (rc) return rc;
+  *result_in_b = (other == b) ? 1 : 0;
+  return LT_OK;
+}
+
+int aux(lt_plan *p, int what, const void *f, void *rho, void *u, double *out, void *stream) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (!f) return fail(LT_ERR_INVALID, "null population buffer");
+  lt::AuxArgs a;
+  memset(&a, 0, sizeof a);
+  a.what = what; a.layout = p->desc.layout;
+  a.f = f; a.rho = rho; a.u = u;
+  a.N = p->N;
+  const long long plane = (long long)p->n0 * p->n1;
+  a.first = plane * p->interior_begin;
+  a.count = plane * (p->interior_end - p->interior_begin);
+  a.partial = p->partial; a.reduce_blocks = kReduceBlocks; a.out = out;
+  a.stream = static_cast<hipStream_t>(stream);
+  const int r = p->unit.aux(a);
+  if (r == lt::kNoKernel) return fail(LT_ERR_UNSUPPORTED, "no auxiliary kernel %d", what);
+  if (r != 0) return fail(LT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)r));
+  return LT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lt_abi_version(void) { return LT_ABI_VERSION; }
+const char *lt_last_error(void) { return g_error; }
+
+int lt_plan_create(const lt_plan_desc *d, lt_plan **out) {
+  if (!d || !out) return fail(LT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (d->abi_version != LT_ABI_VERSION)
+    return fail(LT_ERR_INVALID, "ABI version %d, library is %d", d->abi_version, LT_ABI_VERSION);
+  if (d->stencil < 0 || d->stencil > 2) return fail(LT_ERR_UNSUPPORTED, "stencil %d", d->stencil);
+  if (d->dtype < 0 || d->dtype > 1) return fail(LT_ERR_UNSUPPORTED, "dtype %d (fp32/fp64 only)", d->dtype);
+  if (d->collision < 0 || d->collision > 2) return fail(LT_ERR_UNSUPPORTED, "collision %d", d->collision);
+  const Unit unit = kUnits[d->stencil][d->dtype];
+  if (d->dims != unit.d) return fail(LT_ERR_INVALID, "stencil is %d-dimensional, dims = %d", unit.d, d->dims);
+  if (d->collision == LT_COLLISION_KBC && d->stencil == LT_D3Q19)
+    return fail(LT_ERR_UNSUPPORTED, "KBC collision exists for D2Q9 and D3Q27 only");
+  if (d->layout != LT_LAYOUT_REFERENCE && d->layout != LT_LAYOUT_SLAB)
+    return fail(LT_ERR_INVALID, "layout %d", d->layout);
+  if (d->layout == LT_LAYOUT_SLAB && unit.d != 3) return fail(LT_ERR_UNSUPPORTED, "slab layout is 3-D only");
+  if (d->ghost_planes != 0 && !(d->ghost_planes == 1 && d->layout == LT_LAYOUT_SLAB))
+    return fail(LT_ERR_INVALID, "ghost_planes = %d needs the slab layout", d->ghost_planes);
+  if (d->n_boundaries < 0 || d->n_boundaries > LT_MAX_BOUNDARIES)
+    return fail(LT_ERR_UNSUPPORTED, "%d boundaries (max %d)", d->n_boundaries, LT_MAX_BOUNDARIES);
+  if (d->n_boundaries > 0 && d->layout != LT_LAYOUT_REFERENCE)
+    return fail(LT_ERR_UNSUPPORTED, "boundaries are supported in the reference layout only");
+  for (int a = 0; a < unit.d; ++a)
+    if (d->shape[a] < 1) return fail(LT_ERR_INVALID, "shape[%d] = %lld", a, (long long)d->shape[a]);
+
+  lt_plan *p = new (std::nothrow) lt_plan;
+  if (!p) return fail(LT_ERR_ALLOC, "out of host memory");
+  p->desc = *d;
+  p->unit = unit;
+  p->esize = d->dtype == LT_F32 ? 4 : 8;
+  long long e0, e1, e2;
+  if (unit.d == 2) { e0 = d->shape[1]; e1 = d->shape[0]; e2 = 1; }
+  else if (d->layout == LT_LAYOUT_REFERENCE) { e0 = d->shape[2]; e1 = d->shape[1]; e2 = d->shape[0]; }
+  else { e0 = d->shape[0]; e1 = d->shape[1]; e2 = d->shape[2] + 2 * d->ghost_planes; }
+  if (e0 * e1 * e2 >= (1ll << 31)) {
+    delete p;
+    return fail(LT_ERR_UNSUPPORTED, "%lld nodes per rank exceed the 2^31 index range", e0 * e1 * e2);
+  }
+  p->n0 = (int)e0; p->n1 = (int)e1; p->n2 = (int)e2;
+  p->N = e0 * e1 * e2;
+  p->interior_begin = d->ghost_planes;
+  p->interior_end = p->n2 - d->ghost_planes;
+  p->wide_ok = (e0 % (16 / p->esize)) == 0;
+  p->shift = 0;
+  int n_abb = 0;
+  for (int i = 0; i < d->n_boundaries; ++i) {
+    const int rc = check_boundary(p, d->boundaries[i], n_abb);
+    if (rc) { delete p; return rc; }
+    if (d->boundaries[i].kind == LT_BOUNDARY_ABB_OUTLET) ++n_abb;
+  }
+  const size_t bt_size = d->dtype == LT_F32 ? sizeof(lt::BoundaryTable<float>)
+                                            : sizeof(lt::BoundaryTable<double>);
+  if (hipMalloc(&p->bt, bt_size) != hipSuccess ||
+      hipMalloc((void **)&p->partial, kReduceBlocks * sizeof(double)) != hipSuccess) {
+    lt_plan_destroy(p);
+    return fail(LT_ERR_ALLOC, "hipMalloc of plan scratch failed");
+  }
+  const int rc = d->dtype == LT_F32 ? upload_boundaries<float>(p, nullptr)
+                                    : upload_boundaries<double>(p, nullptr);
+  if (rc) { lt_plan_destroy(p); return rc; }
+  *out = p;
+  return LT_OK;
+}
+
+int lt_plan_destroy(lt_plan *p) {
+  if (!p) return LT_OK;
+  if (p->node) (void)hipFree(p->node);
+  if (p->nsm_bits) (void)hipFree(p->nsm_bits);
+  if (p->bt) (void)hipFree(p->bt);
+  if (p->partial) (void)hipFree(p->partial);
+  delete p;
+  return LT_OK;
+}
+
+int lt_plan_set_masks(lt_plan *p, const uint8_t *ncm, const uint8_t *nsm, void *stream) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (p->desc.layout != LT_LAYOUT_REFERENCE)
+    return fail(LT_ERR_UNSUPPORTED, "masks are supported in the reference layout only");
+  if (!ncm && !nsm) {
+    if (p->desc.n_boundaries > 0)
+      return fail(LT_ERR_INVALID, "a plan with boundaries needs a no_collision_mask");
+    p->masked = 0;
+    return LT_OK;
+  }
+  if (!p->node) LT_HIP(hipMalloc((void **)&p->node, (size_t)p->N));
+  if (nsm && !p->nsm_bits) LT_HIP(hipMalloc((void **)&p->nsm_bits, (size_t)p->N * sizeof(unsigned)));
+  const unsigned grid = (unsigned)((p->N + lt::kThreads - 1) / lt::kThreads);
+  hipLaunchKernelGGL(lt::compile_masks_kernel, dim3(grid), dim3(lt::kThreads), 0,
+                     static_cast<hipStream_t>(stream), ncm, nsm, p->unit.q, p->N, p->node,
+                     nsm ? p->nsm_bits : nullptr);
+  LT_HIP(hipGetLastError());
+  p->masked = 1;
+  return LT_OK;
+}
+
+int lt_plan_update_boundary(lt_plan *p, int32_t index, const lt_boundary_desc *b, void *stream) {
+  if (!p || !b) return fail(LT_ERR_INVALID, "null argument");
+  if (index < 0 || index >= p->desc.n_boundaries) return fail(LT_ERR_INVALID, "boundary index %d", index);
+  if (b->kind != p->desc.boundaries[index].kind)
+    return fail(LT_ERR_INVALID, "boundary %d: kind cannot change (%d -> %d)", index,
+                p->desc.boundaries[index].kind, b->kind);
+  p->desc.boundaries[index] = *b;
+  return p->desc.dtype == LT_F32 ? upload_boundaries<float>(p, static_cast<hipStream_t>(stream))
+                                 : upload_boundaries<double>(p, static_cast<hipStream_t>(stream));
+}
+
+int lt_collide(lt_plan *p, const void *f, void *o, double tau, void *s) {
+  return step(p, lt::kCollideOnly, f, o, tau, p ? p->interior_begin : 0, p ? p->interior_end : 0, s);
+}
+int lt_stream(lt_plan *p, const void *f, void *o, void *s) {
+  return step(p, lt::kStreamOnly, f, o, 1.0, p ? p->interior_begin : 0, p ? p->interior_end : 0, s);
+}
+int lt_stream_collide(lt_plan *p, const void *f, void *o, double tau, void *s) {
+  return step(p, lt::kFused, f, o, tau, p ? p->interior_begin : 0, p ? p->interior_end : 0, s);
+}
+int lt_collide_planes(lt_plan *p, const void *f, void *o, double tau, int64_t b, int64_t e, void *s) {
+  return step(p, lt::kCollideOnly, f, o, tau, b, e, s);
+}
+int lt_stream_planes(lt_plan *p, const void *f, void *o, int64_t b, int64_t e, void *s) {
+  return step(p, lt::kStreamOnly, f, o, 1.0, b, e, s);
+}
+int lt_stream_collide_planes(lt_plan *p, const void *f, void *o, double tau, int64_t b, int64_t e,
+                             void *s) {
+  return step(p, lt::kFused, f, o, tau, b, e, s);
+}
+
+int lt_run(lt_plan *p, void *a, void *b, double tau, int64_t n, void *s, int32_t *r) {
+  return run(p, false, a, b, tau, n, s, r);
+}
+int lt_continue(lt_plan *p, void *a, void *b, double tau, int64_t n, void *s, int32_t *r) {
+  return run(p, true, a, b, tau, n, s, r);
+}
+
+int lt_macroscopic(lt_plan *p, const void *f, void *rho, void *u, void *s) {
+  if (!rho && !u) return fail(LT_ERR_INVALID, "both outputs null");
+  return aux(p, 0, f, rho, u, nullptr, s);
+}
+int lt_equilibrium(lt_plan *p, const void *rho, const void *u, void *feq, void *s) {
+  if (!rho || !u) return fail(LT_ERR_INVALID, "null rho/u");
+  return aux(p, 1, feq, const_cast<void *>(rho), const_cast<void *>(u), nullptr, s);
+}
+int lt_kinetic_energy(lt_plan *p, const void *f, double *out, void *s) {
+  if (!out) return fail(LT_ERR_INVALID, "null output");
+  return aux(p, 2, f, nullptr, nullptr, out, s);
+}
+int lt_mass(lt_plan *p, const void *f, double *out, void *s) {
+  if (!out) return fail(LT_ERR_INVALID, "null output");
+  return aux(p, 3, f, nullptr, nullptr, out, s);
+}
+
+int lt_plan_kernel_info(lt_plan *p, int32_t *vec, int32_t *tpb, int64_t *blocks) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  const int v = p->wide_ok ? 16 / p->esize : 1;
+  if (vec) *vec = v;
+  if (tpb) *tpb = lt::kThreads;
+  if (blocks) {
+    const long long nodes = (long long)p->n0 * p->n1 * (p->interior_end - p->interior_begin);
+    *blocks = (nodes / v + lt::kThreads - 1) / lt::kThreads;
+  }
+  return LT_OK;
+}
+
+const char *lt_plan_kernel_name(lt_plan *p) {
+  if (!p) return "";
+  lt::StepArgs a;
+  memset(&a, 0, sizeof a);
+  a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = lt::kFused;
+  a.masked = p->masked; a.wide = p->wide_ok;
+  a.shift = (a.wide && !a.masked && a.coll == LT_COLLISION_BGK) ? p->shift : 0;
+  const char *n = p->unit.name(a);
+  snprintf(p->kernel_name, sizeof p->kernel_name, "%s", n ? n : "");
+  return p->kernel_name;
+}
+
+int lt_plan_set_shift_policy(lt_plan *p, int32_t policy) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (policy < 0 || policy > 2) return fail(LT_ERR_INVALID, "shift policy %d", policy);
+  p->shift = policy;
+  return LT_OK;
+}
+
+}  // extern "C"

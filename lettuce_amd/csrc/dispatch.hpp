@@ -1,0 +1,60 @@
+// Type-erased launch interface between api.hip (plan handling, C ABI) and the
+// per-(stencil, dtype) translation units that instantiate the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lt {
+
+enum StepMode { kFused = 0, kCollideOnly = 1, kStreamOnly = 2 };
+
+struct StepArgs {
+  const void *in;
+  void *out;
+  int n0, n1, n2;        // memory extents (n2 incl. ghost planes)
+  int p_begin, planes;   // a2 plane range of this launch
+  int wrap2;
+  double tau;
+  const unsigned char *node;
+  const unsigned *nsm_bits;
+  const void *bt;        // BoundaryTable<T>* (device)
+  int nb;
+  int layout, coll, mode, masked, wide, shift;
+  hipStream_t stream;
+};
+
+struct AuxArgs {
+  int what;              // 0 macroscopic, 1 equilibrium, 2 kinetic energy, 3 mass
+  int layout;
+  const void *f;         // populations (what 0, 2, 3) / feq output (what 1; cast away const)
+  void *rho;             // what 0: out, what 1: in
+  void *u;               // what 0: out, what 1: in
+  long long N;           // nodes per population (incl. ghost planes)
+  long long first, count;  // node range reduced (what 2, 3)
+  double *partial;       // plan scratch, >= reduce_blocks doubles
+  int reduce_blocks;
+  double *out;           // device scalar
+  hipStream_t stream;
+};
+
+typedef int (*StepFn)(const StepArgs &);
+typedef int (*AuxFn)(const AuxArgs &);
+typedef const char *(*NameFn)(const StepArgs &);
+
+// one set per translation unit inst_<stencil>_<dtype>.hip
+#define LT_DECLARE_UNIT(tag)              \
+  int step_##tag(const StepArgs &);       \
+  int aux_##tag(const AuxArgs &);         \
+  const char *name_##tag(const StepArgs &);
+
+LT_DECLARE_UNIT(d2q9_f32)
+LT_DECLARE_UNIT(d2q9_f64)
+LT_DECLARE_UNIT(d3q19_f32)
+LT_DECLARE_UNIT(d3q19_f64)
+LT_DECLARE_UNIT(d3q27_f32)
+LT_DECLARE_UNIT(d3q27_f64)
+
+// returns -1 when the combination has no instantiated kernel, else the hipError_t of the launch
+constexpr int kNoKernel = -1;
+
+}  // namespace lt

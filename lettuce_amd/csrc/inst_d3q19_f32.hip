@@ -1,0 +1,7 @@
+// Kernel instantiations: D3Q19, float.
+#define LT_S lt::D3Q19
+#define LT_T float
+#define LT_TAG d3q19_f32
+#define LT_HAS_KBC 0
+#define LT_IS_3D 1
+#include "unit.inc"

@@ -1,0 +1,668 @@
+// Hand-written gfx950 kernels of the stream-and-collide hot path.
+//
+// One kernel template covers the three operators the host composes
+// (see include/lettuce_hip.h):
+//   STREAM && COLLIDE   f*_out = B(C(S(f*_in)))   fused pull scheme (the hot kernel)
+//   !STREAM && COLLIDE  f*_out = B(C(f_in))       prologue of lt_run
+//   STREAM && !COLLIDE  f_out  = S(f*_in)         epilogue of lt_run
+// where S = Simulation._stream (lettuce/_simulation.py:160-175), C = the collision operator
+// (bgk_collision.py:17-22 / kbc_collision.py:96-160 with quadratic_equilibrium.py:11-25 and
+// Flow.rho/j/u, _flow.py:136-172) and B = the boundaries applied in index order
+// (_simulation.py:177-189).
+//
+// Design for MI355X (HBM-bound: 2*q*sizeof(T) bytes per node, ~2-4 flop/byte, no MFMA):
+//  * SoA per velocity; a thread owns VEC consecutive nodes along the contiguous axis a0
+//    (VEC*sizeof(T) = 16 B), so every population is read and written with one 16-byte
+//    access per lane = 1 KiB per wave instruction, fully coalesced.
+//  * Pull scheme: each slot of f*_in is read by exactly one thread, each slot of the output
+//    is written by exactly one thread (no atomics, no write races, no halo re-reads).  The
+//    +-1 shift along a0 is resolved in registers from the aligned 16-byte load plus one
+//    neighbour element (or a cross-lane shift), so HBM traffic stays at the algorithmic
+//    2*q*sizeof(T) per node.
+//  * Everything between the loads and the stores lives in VGPRs; the lattice is a template
+//    parameter so e_q, w_q and the opposite table are folded into the instruction stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lattice.hpp"
+
+namespace lt {
+
+constexpr int kThreads = 256;
+constexpr int kMaxB = 7;   // == LT_MAX_BOUNDARIES
+
+// boundary kinds (== lt_boundary_kind)
+constexpr int kBounceBack = 1, kEquilibrium = 2, kAbbOutlet = 3;
+
+template <typename T>
+struct BoundaryTable {
+  int kind[kMaxB + 1];       // [1..nb]
+  int mem_axis[kMaxB + 1];   // ABB: memory axis of the outlet normal
+  int side[kMaxB + 1];       // ABB: +1 / -1 along that memory axis
+  int plane[kMaxB + 1];      // ABB: memory coordinate of the outlet plane
+  int nbr[kMaxB + 1];        // ABB: memory coordinate of the plane next to it (inside)
+  T feq[kMaxB + 1][27];      // EQUILIBRIUM, uniform
+  const T *field[kMaxB + 1]; // EQUILIBRIUM, per node [q][N] (or null)
+};
+
+template <typename T>
+struct KParams {
+  const T *in;
+  T *out;
+  int n0, n1, n2;            // memory extents; n2 includes ghost planes
+  int nv0;                   // n0 / VEC
+  int p_begin;               // first a2 plane of this launch
+  int wrap2;                 // periodic wrap along a2 (0 with ghost planes)
+  long long N;               // n0*n1*n2 = stride between populations
+  unsigned nvec_total;       // threads doing work: nv0 * n1 * planes
+  T tau_inv;                 // BGK: 1/tau
+  T beta, inv_beta;          // KBC: 1/(2 tau), 1/beta
+  const unsigned char *node; // [N] boundary index | 0x80 if any no-streaming bit (or null)
+  const unsigned *nsm_bits;  // [N] bit q set: population q keeps its value (or null)
+  const BoundaryTable<T> *bt;
+  int nb;
+};
+
+// ---- constants the reference builds from cs = 1/np.sqrt(3.0) (lettuce/_stencil.py:17) ----
+// cs**2 evaluates to 0.33333333333333337 in double; keep that value, not 1/3.
+constexpr double kCs = 0.57735026918962584;   // 1/sqrt(3) rounded to double
+constexpr double kCs2 = kCs * kCs;
+constexpr double kCs4 = kCs2 * kCs2;
+
+// ---- 16-byte vector access ---------------------------------------------------------------
+template <typename T, int VEC> struct Vec;
+template <> struct Vec<float, 4> {
+  typedef float type __attribute__((ext_vector_type(4)));
+  typedef float utype __attribute__((ext_vector_type(4), aligned(4)));
+  typedef unsigned char mtype __attribute__((ext_vector_type(4)));
+};
+template <> struct Vec<double, 2> {
+  typedef double type __attribute__((ext_vector_type(2)));
+  typedef double utype __attribute__((ext_vector_type(2), aligned(8)));
+  typedef unsigned char mtype __attribute__((ext_vector_type(2)));
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ void vload(const T *__restrict__ p, T (&r)[VEC]) {
+  if constexpr (VEC == 1) {
+    r[0] = *p;
+  } else {
+    const typename Vec<T, VEC>::type v = *reinterpret_cast<const typename Vec<T, VEC>::type *>(p);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) r[k] = v[k];
+  }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void vload_unaligned(const T *__restrict__ p, T (&r)[VEC]) {
+  const typename Vec<T, VEC>::utype v = *reinterpret_cast<const typename Vec<T, VEC>::utype *>(p);
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) r[k] = v[k];
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void vstore(T *__restrict__ p, const T (&r)[VEC]) {
+  if constexpr (VEC == 1) {
+    *p = r[0];
+  } else {
+    typename Vec<T, VEC>::type v;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] = r[k];
+    *reinterpret_cast<typename Vec<T, VEC>::type *>(p) = v;
+  }
+}
+
+// ---- node coordinates -----------------------------------------------------------------------
+struct Coord {
+  int c0, c1, c2;      // own (first of VEC along a0)
+  int c1m, c1p;        // periodic neighbours along a1
+  int c2m, c2p;        // neighbours along a2 (periodic iff wrap2)
+};
+
+template <typename T>
+__device__ __forceinline__ Coord make_coord(const KParams<T> &p, int c0, int c1, int c2) {
+  Coord c;
+  c.c0 = c0; c.c1 = c1; c.c2 = c2;
+  c.c1m = c1 == 0 ? p.n1 - 1 : c1 - 1;
+  c.c1p = c1 == p.n1 - 1 ? 0 : c1 + 1;
+  c.c2m = c2 - 1;
+  c.c2p = c2 + 1;
+  if (p.wrap2) {
+    if (c.c2m < 0) c.c2m = p.n2 - 1;
+    if (c.c2p == p.n2) c.c2p = 0;
+  }
+  return c;
+}
+
+// ---- gather: post-streaming populations of VEC nodes ------------------------------------
+// f_q(x) = f*_q(x - e_q), periodic (Simulation._stream: torch.roll by +e_q,
+// lettuce/_simulation.py:156-158,164-175).  SHIFT selects how the a0 shift is resolved:
+//   0: aligned 16-B load + one neighbour element load
+//   1: unaligned 16-B load (row ends handled separately)
+//   2: aligned 16-B load + cross-lane shift (ds_bpermute), neighbour element only at wave/row edges
+template <typename T, class S, int LAYOUT, bool STREAM, int VEC, int SHIFT>
+__device__ __forceinline__ void gather(const KParams<T> &p, const Coord &c, T (&f)[S::Q][VEC]) {
+  using M = MemMap<S, LAYOUT>;
+  const int n0 = p.n0, n1 = p.n1;
+  const unsigned own = (unsigned)(c.c2 * n1 + c.c1) * (unsigned)n0 + (unsigned)c.c0;
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    const T *__restrict__ src = p.in + (long long)q * p.N;
+    if constexpr (!STREAM) {
+      vload<T, VEC>(src + own, f[q]);
+    } else {
+      constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1), e2 = M::e(q, 2);
+      const int s1 = e1 == 0 ? c.c1 : (e1 > 0 ? c.c1m : c.c1p);
+      const int s2 = e2 == 0 ? c.c2 : (e2 > 0 ? c.c2m : c.c2p);
+      const unsigned row = (unsigned)(s2 * n1 + s1) * (unsigned)n0;
+      if constexpr (e0 == 0) {
+        vload<T, VEC>(src + row + c.c0, f[q]);
+      } else if constexpr (VEC == 1) {
+        const int s0 = e0 > 0 ? (c.c0 == 0 ? n0 - 1 : c.c0 - 1) : (c.c0 == n0 - 1 ? 0 : c.c0 + 1);
+        f[q][0] = src[row + s0];
+      } else if constexpr (e0 > 0) {
+        // want src[c0-1], src[c0], ..., src[c0+VEC-2]
+        if constexpr (SHIFT == 1) {
+          if (c.c0 != 0) {
+            vload_unaligned<T, VEC>(src + row + c.c0 - 1, f[q]);
+          } else {
+            T a[VEC];
+            vload<T, VEC>(src + row, a);
+            f[q][0] = src[row + n0 - 1];
+#pragma unroll
+            for (int k = 1; k < VEC; ++k) f[q][k] = a[k - 1];
+          }
+        } else {
+          T a[VEC];
+          vload<T, VEC>(src + row + c.c0, a);
+          T nb;
+          if constexpr (SHIFT == 2) {
+            nb = __shfl_up(a[VEC - 1], 1);
+            if ((threadIdx.x & 63) == 0 || c.c0 == 0) nb = src[row + (c.c0 == 0 ? n0 - 1 : c.c0 - 1)];
+          } else {
+            nb = src[row + (c.c0 == 0 ? n0 - 1 : c.c0 - 1)];
+          }
+          f[q][0] = nb;
+#pragma unroll
+          for (int k = 1; k < VEC; ++k) f[q][k] = a[k - 1];
+        }
+      } else {
+        // want src[c0+1], ..., src[c0+VEC]
+        const bool last = c.c0 + VEC == n0;
+        if constexpr (SHIFT == 1) {
+          if (!last) {
+            vload_unaligned<T, VEC>(src + row + c.c0 + 1, f[q]);
+          } else {
+            T a[VEC];
+            vload<T, VEC>(src + row + c.c0, a);
+#pragma unroll
+            for (int k = 0; k < VEC - 1; ++k) f[q][k] = a[k + 1];
+            f[q][VEC - 1] = src[row];
+          }
+        } else {
+          T a[VEC];
+          vload<T, VEC>(src + row + c.c0, a);
+          T nb;
+          if constexpr (SHIFT == 2) {
+            nb = __shfl_down(a[0], 1);
+            if ((threadIdx.x & 63) == 63 || last) nb = src[row + (last ? 0 : c.c0 + VEC)];
+          } else {
+            nb = src[row + (last ? 0 : c.c0 + VEC)];
+          }
+#pragma unroll
+          for (int k = 0; k < VEC - 1; ++k) f[q][k] = a[k + 1];
+          f[q][VEC - 1] = nb;
+        }
+      }
+    }
+  });
+}
+
+// destination-side no-streaming mask: slot (q, x) keeps the value it had before streaming
+// (lettuce/_simulation.py:171-174)
+template <typename T, class S, int VEC, int k>
+__device__ __forceinline__ void keep_unstreamed(const KParams<T> &p, unsigned own,
+                                                T (&f)[S::Q][VEC]) {
+  const unsigned bits = p.nsm_bits[own + k];
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    if constexpr (q > 0) {   // population 0 never moves (_simulation.py:165)
+      if (bits & (1u << q)) f[q][k] = p.in[(long long)q * p.N + own + k];
+    }
+  });
+}
+
+// ---- moments (Flow.rho / Flow.j / Flow.u, lettuce/_flow.py:136-138,152-172) ---------------
+// j += e_q * v along the three memory axes, all signs folded at compile time
+template <class S, int LAYOUT, int q, typename T>
+__device__ __forceinline__ void add_momentum(T (&j)[3], T v) {
+  using M = MemMap<S, LAYOUT>;
+  static_for<3>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    constexpr int e = M::e(q, m);
+    if constexpr (e > 0) j[m] += v;
+    else if constexpr (e < 0) j[m] -= v;
+  });
+}
+// e_q . u
+template <class S, int LAYOUT, int q, typename T>
+__device__ __forceinline__ T dot_e(const T (&u)[3]) {
+  using M = MemMap<S, LAYOUT>;
+  T r = T(0);
+  static_for<3>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    constexpr int e = M::e(q, m);
+    if constexpr (e > 0) r += u[m];
+    else if constexpr (e < 0) r -= u[m];
+  });
+  return r;
+}
+
+template <typename T, class S, int LAYOUT, int VEC, int k>
+__device__ __forceinline__ void moments(const T (&f)[S::Q][VEC], T &rho, T (&j)[3]) {
+  rho = T(0);
+  j[0] = j[1] = j[2] = T(0);
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    const T v = f[q][k];
+    rho += v;
+    add_momentum<S, LAYOUT, q>(j, v);
+  });
+}
+
+// QuadraticEquilibrium (lettuce/ext/_equilibrium/quadratic_equilibrium.py:15-24), u along
+// memory axes (the dot products are invariant under the axis permutation)
+template <typename T, class S, int LAYOUT, int q>
+__device__ __forceinline__ T feq_q(T rho, const T (&u)[3], T uxu) {
+  const T exu = dot_e<S, LAYOUT, q>(u);
+  const T a = (T(2) * exu - uxu) * T(1.0 / (2.0 * kCs2));
+  const T b = exu * T(1.0 / kCs2);
+  return T(S::W[q]) * (rho * (a + T(0.5) * (b * b) + T(1)));
+}
+
+// ---- collisions ---------------------------------------------------------------------------
+template <typename T, class S, int LAYOUT, int VEC, int k>
+__device__ __forceinline__ void collide_bgk(T (&f)[S::Q][VEC], T tau_inv) {
+  T rho, j[3], u[3];
+  moments<T, S, LAYOUT, VEC, k>(f, rho, j);
+  u[0] = j[0] / rho; u[1] = j[1] / rho; u[2] = j[2] / rho;
+  const T uxu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    const T feq = feq_q<T, S, LAYOUT, q>(rho, u, uxu);
+    f[q][k] = f[q][k] - tau_inv * (f[q][k] - feq);
+  });
+}
+
+// the KBC "s" vector from the second moments of a population set g
+// (lettuce/ext/_collision/kbc_collision.py:25-39 moments, :44-94 s_i)
+template <typename T, class S>
+struct KbcS {
+  T s0, sa, sb, sc, pxy, pxz, pyz;   // 3-D: s0, s1(=s2), s3(=s4), s5(=s6), s15, s11, s7
+  template <int q>
+  __device__ __forceinline__ T get() const {
+    if constexpr (S::D == 3) {
+      if constexpr (q == 0) return s0;
+      else if constexpr (q <= 2) return sa;
+      else if constexpr (q <= 4) return sb;
+      else if constexpr (q <= 6) return sc;
+      else if constexpr (q <= 8) return pyz;
+      else if constexpr (q <= 10) return -pyz;
+      else if constexpr (q <= 12) return pxz;
+      else if constexpr (q <= 14) return -pxz;
+      else if constexpr (q <= 16) return pxy;
+      else if constexpr (q <= 18) return -pxy;
+      else return T(0);
+    } else {
+      if constexpr (q == 0) return s0;
+      else if constexpr (q == 1 || q == 3) return sa;
+      else if constexpr (q == 2 || q == 4) return sb;
+      else if constexpr (q == 5 || q == 7) return pxy;
+      else return -pxy;
+    }
+  }
+};
+
+template <typename T, class S, class G>
+__device__ __forceinline__ KbcS<T, S> kbc_s(const G &g) {
+  // g(q) returns population q; logical axes (KBC is written in x,y,z)
+  T rho = T(0), xx = T(0), yy = T(0), zz = T(0), xy = T(0), xz = T(0), yz = T(0);
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int ex = S::E[q][0], ey = S::E[q][1], ez = S::E[q][2];
+    const T v = g(qc);
+    rho += v;
+    if constexpr (ex != 0) xx += v;
+    if constexpr (ey != 0) yy += v;
+    if constexpr (ez != 0) zz += v;
+    if constexpr (ex * ey > 0) xy += v; else if constexpr (ex * ey < 0) xy -= v;
+    if constexpr (ex * ez > 0) xz += v; else if constexpr (ex * ez < 0) xz -= v;
+    if constexpr (ey * ez > 0) yz += v; else if constexpr (ey * ez < 0) yz -= v;
+  });
+  xx /= rho; yy /= rho; xy /= rho;
+  KbcS<T, S> s;
+  if constexpr (S::D == 3) {
+    zz /= rho; xz /= rho; yz /= rho;
+    const T Tr = xx + yy + zz, nxz = xx - zz, nyz = yy - zz;
+    s.s0 = rho * -Tr;
+    s.sa = T(1. / 6.) * rho * (T(2) * nxz - nyz + Tr);
+    s.sb = T(1. / 6.) * rho * (T(2) * nyz - nxz + Tr);
+    s.sc = T(1. / 6.) * rho * (-nxz - nyz + Tr);
+    s.pyz = T(0.25) * rho * yz;
+    s.pxz = T(0.25) * rho * xz;
+    s.pxy = T(0.25) * rho * xy;
+  } else {
+    const T Tr = xx + yy, n = xx - yy;
+    s.s0 = rho * -Tr;
+    s.sa = T(0.5) * rho * (T(0.5) * (Tr + n));
+    s.sb = T(0.5) * rho * (T(0.5) * (Tr - n));
+    s.sc = T(0);
+    s.pxy = T(0.25) * rho * xy;
+    s.pxz = s.pyz = T(0);
+  }
+  return s;
+}
+
+template <typename T, class S, int LAYOUT, int VEC, int k>
+__device__ __forceinline__ void collide_kbc(T (&f)[S::Q][VEC], T beta, T inv_beta) {
+  static_assert(S::Q == 9 || S::Q == 27, "KBC exists for D2Q9 and D3Q27 only (kbc_collision.py:100-128)");
+  T rho, j[3], u[3];
+  moments<T, S, LAYOUT, VEC, k>(f, rho, j);
+  u[0] = j[0] / rho; u[1] = j[1] / rho; u[2] = j[2] / rho;
+  const T uxu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+  T feq[S::Q];
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    feq[q] = feq_q<T, S, LAYOUT, q>(rho, u, uxu);
+  });
+  const KbcS<T, S> sf = kbc_s<T, S>([&](auto qc) { return f[decltype(qc)::value][k]; });
+  const KbcS<T, S> se = kbc_s<T, S>([&](auto qc) { return feq[decltype(qc)::value]; });
+  T sum_s = T(0), sum_h = T(0);
+  T ds[S::Q], dh[S::Q];
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    ds[q] = sf.template get<q>() - se.template get<q>();
+    dh[q] = f[q][k] - feq[q] - ds[q];
+    sum_s += ds[q] * dh[q] / feq[q];
+    sum_h += dh[q] * dh[q] / feq[q];
+  });
+  T gamma = inv_beta - (T(2) - inv_beta) * sum_s / sum_h;
+  if (gamma < T(1e-15)) gamma = T(2);
+  if (gamma != gamma) gamma = T(2);
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    f[q][k] = f[q][k] - beta * (T(2) * ds[q] + gamma * dh[q]);
+  });
+}
+
+// ---- boundaries -------------------------------------------------------------------------
+// BounceBackBoundary: f <- f[opposite] (lettuce/ext/_boundary/bounce_back_boundary.py:17-18)
+template <typename T, class S, int VEC, int k>
+__device__ __forceinline__ void bounce_back(T (&f)[S::Q][VEC]) {
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int o = S::OPP[q];
+    if constexpr (q < o) {
+      const T t = f[q][k];
+      f[q][k] = f[o][k];
+      f[o][k] = t;
+    }
+  });
+}
+
+// (rho, j) of the node next to an outlet plane, as Flow.rho()/Flow.u() would see it when the
+// AntiBounceBackOutlet with index `slot` is evaluated: after collision (which conserves both)
+// and after the boundaries with a lower index (anti_bounce_back_outlet.py:77-80).
+template <typename T, class S, int LAYOUT, bool STREAM, bool MASKED>
+__device__ __forceinline__ void neighbour_moments(const KParams<T> &p, int c0, int c1, int c2, int slot,
+                                  T &rho, T (&j)[3]) {
+  const Coord c = make_coord(p, c0, c1, c2);
+  T g[S::Q][1];
+  gather<T, S, LAYOUT, STREAM, 1, 0>(p, c, g);
+  const unsigned own = (unsigned)(c2 * p.n1 + c1) * (unsigned)p.n0 + (unsigned)c0;
+  int b = 0;
+  if constexpr (MASKED) {
+    const unsigned char nd = p.node[own];
+    b = nd & 0x7f;
+    if constexpr (STREAM) {
+      if (nd & 0x80) keep_unstreamed<T, S, 1, 0>(p, own, g);
+    }
+  }
+  moments<T, S, LAYOUT, 1, 0>(g, rho, j);
+  if (b > 0 && b < slot) {
+    const int kind = p.bt->kind[b];
+    if (kind == kBounceBack) {
+      j[0] = -j[0]; j[1] = -j[1]; j[2] = -j[2];
+    } else if (kind == kEquilibrium) {
+      const T *fld = p.bt->field[b];
+      rho = T(0); j[0] = j[1] = j[2] = T(0);
+      static_for<S::Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const T v = fld ? fld[(long long)q * p.N + own] : p.bt->feq[b][q];
+        rho += v;
+        add_momentum<S, LAYOUT, q>(j, v);
+      });
+    }
+  }
+}
+
+// AntiBounceBackOutlet (lettuce/ext/_boundary/anti_bounce_back_outlet.py:72-91) on one node
+// of the outlet plane.
+template <typename T, class S, int LAYOUT, bool STREAM, bool MASKED, int VEC, int k>
+__device__ __forceinline__ void abb_outlet(const KParams<T> &p, int slot, int c0k, int c1,
+                                           int c2, T (&f)[S::Q][VEC]) {
+  using M = MemMap<S, LAYOUT>;
+  const int ax = p.bt->mem_axis[slot], side = p.bt->side[slot], nbr = p.bt->nbr[slot];
+  T rho, j[3], rn, jn[3];
+  moments<T, S, LAYOUT, VEC, k>(f, rho, j);
+  neighbour_moments<T, S, LAYOUT, STREAM, MASKED>(p, ax == 0 ? nbr : c0k, ax == 1 ? nbr : c1,
+                                                   ax == 2 ? nbr : c2, slot, rn, jn);
+  T uw[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const T u = j[m] / rho, un = jn[m] / rn;
+    uw[m] = u + T(0.5) * (u - un);
+  }
+  const T nrm = sqrt(uw[0] * uw[0] + uw[1] * uw[1] + uw[2] * uw[2]) / T(kCs);
+  const T nrm2 = nrm * nrm;
+  T fresh[S::Q];
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    const int en = (ax == 0 ? M::e(q, 0) : (ax == 1 ? M::e(q, 1) : M::e(q, 2))) * side;
+    const T eu = dot_e<S, LAYOUT, q>(uw);
+    fresh[q] = en == 1 ? -f[q][k] + T(S::W[q]) * rho * (T(2) + eu * eu / T(kCs4) - nrm2) : T(0);
+  });
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    const int en = (ax == 0 ? M::e(q, 0) : (ax == 1 ? M::e(q, 1) : M::e(q, 2))) * side;
+    if (en == 1) f[S::OPP[q]][k] = fresh[q];
+  });
+}
+
+// ---- the kernel ---------------------------------------------------------------------------
+template <typename T, class S, int LAYOUT, int COLL, bool STREAM, bool COLLIDE, bool MASKED,
+          int VEC, int SHIFT>
+__global__ void __launch_bounds__(kThreads) lbm_kernel(const KParams<T> p) {
+  const unsigned v = blockIdx.x * (unsigned)kThreads + threadIdx.x;
+  if (v >= p.nvec_total) return;
+  const unsigned rowid = v / (unsigned)p.nv0;
+  const int c0 = (int)(v - rowid * (unsigned)p.nv0) * VEC;
+  const int r2 = (int)(rowid / (unsigned)p.n1);
+  const int c1 = (int)(rowid - (unsigned)r2 * (unsigned)p.n1);
+  const int c2 = p.p_begin + r2;
+  const Coord c = make_coord(p, c0, c1, c2);
+  const unsigned own = (unsigned)(c2 * p.n1 + c1) * (unsigned)p.n0 + (unsigned)c0;
+
+  T f[S::Q][VEC];
+  gather<T, S, LAYOUT, STREAM, VEC, SHIFT>(p, c, f);
+
+  unsigned char nd[VEC];
+  if constexpr (MASKED) {
+    if constexpr (VEC == 1) {
+      nd[0] = p.node[own];
+    } else {
+      const typename Vec<T, VEC>::mtype m =
+          *reinterpret_cast<const typename Vec<T, VEC>::mtype *>(p.node + own);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) nd[k] = m[k];
+    }
+    if constexpr (STREAM) {
+      static_for<VEC>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (nd[k] & 0x80) keep_unstreamed<T, S, VEC, k>(p, own, f);
+      });
+    }
+  }
+
+  if constexpr (COLLIDE) {
+    static_for<VEC>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      int b = 0;
+      if constexpr (MASKED) b = nd[k] & 0x7f;
+      if (b == 0) {
+        if constexpr (COLL == 1) collide_bgk<T, S, LAYOUT, VEC, k>(f, p.tau_inv);
+        if constexpr (COLL == 2) collide_kbc<T, S, LAYOUT, VEC, k>(f, p.beta, p.inv_beta);
+      }
+      if constexpr (MASKED) {
+        for (int slot = 1; slot <= p.nb; ++slot) {
+          const int kind = p.bt->kind[slot];
+          if (kind == kAbbOutlet) {
+            // applies on the whole outlet plane, whatever the node's index: the reference
+            // mutates flow.f in place and the masked torch.where is then a no-op
+            // (anti_bounce_back_outlet.py:81-91, _simulation.py:186-188)
+            const int ax = p.bt->mem_axis[slot];
+            const int coord = ax == 0 ? c0 + k : (ax == 1 ? c1 : c2);
+            if (coord == p.bt->plane[slot])
+              abb_outlet<T, S, LAYOUT, STREAM, MASKED, VEC, k>(p, slot, c0 + k, c1, c2, f);
+          } else if (b == slot) {
+            if (kind == kBounceBack) {
+              bounce_back<T, S, VEC, k>(f);
+            } else if (kind == kEquilibrium) {
+              const T *fld = p.bt->field[slot];
+              static_for<S::Q>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                f[q][k] = fld ? fld[(long long)q * p.N + own + k] : p.bt->feq[slot][q];
+              });
+            }
+          }
+        }
+      }
+    });
+  }
+
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    vstore<T, VEC>(p.out + (long long)q * p.N + own, f[q]);
+  });
+}
+
+// ---- auxiliary kernels --------------------------------------------------------------------
+// rho [N], u [d][N] (logical axis order) from f  -- Flow.rho / Flow.u
+template <typename T, class S, int LAYOUT>
+__global__ void __launch_bounds__(kThreads) macroscopic_kernel(const T *__restrict__ f,
+                                                               T *__restrict__ rho_out,
+                                                               T *__restrict__ u_out,
+                                                               long long N) {
+  using M = MemMap<S, LAYOUT>;
+  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= N) return;
+  T g[S::Q][1];
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    g[q][0] = f[(long long)q * N + i];
+  });
+  T rho, j[3];
+  moments<T, S, LAYOUT, 1, 0>(g, rho, j);
+  if (rho_out) rho_out[i] = rho;
+  if (u_out) {
+#pragma unroll
+    for (int a = 0; a < S::D; ++a) u_out[(long long)a * N + i] = j[M::memory(a)] / rho;
+  }
+}
+
+// feq [q][N] from rho [N], u [d][N]  -- QuadraticEquilibrium.__call__
+template <typename T, class S, int LAYOUT>
+__global__ void __launch_bounds__(kThreads) equilibrium_kernel(const T *__restrict__ rho_in,
+                                                               const T *__restrict__ u_in,
+                                                               T *__restrict__ feq_out,
+                                                               long long N) {
+  using M = MemMap<S, LAYOUT>;
+  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= N) return;
+  const T rho = rho_in[i];
+  T u[3] = {T(0), T(0), T(0)};
+#pragma unroll
+  for (int a = 0; a < S::D; ++a) u[M::memory(a)] = u_in[(long long)a * N + i];
+  const T uxu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    feq_out[(long long)q * N + i] = feq_q<T, S, LAYOUT, q>(rho, u, uxu);
+  });
+}
+
+// wavefront (64-lane) + workgroup reduction of a double; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v) {
+  __shared__ double part[kThreads / 64];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) part[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) s += part[w];
+  }
+  return s;
+}
+
+// per-block partial sums of 0.5*u.u (MODE 0) or of sum_q f (MODE 1) over the planes
+// [p_begin, p_begin + planes) of a2; fixed grid -> fixed summation order.
+template <typename T, class S, int LAYOUT, int MODE>
+__global__ void __launch_bounds__(kThreads) reduce_kernel(const T *__restrict__ f, long long N,
+                                                          long long first, long long count,
+                                                          double *__restrict__ partial) {
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < count;
+       i += (long long)gridDim.x * kThreads) {
+    T g[S::Q][1];
+    static_for<S::Q>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      g[q][0] = f[(long long)q * N + first + i];
+    });
+    T rho, j[3];
+    moments<T, S, LAYOUT, 1, 0>(g, rho, j);
+    if constexpr (MODE == 0) {
+      const T ux = j[0] / rho, uy = j[1] / rho, uz = j[2] / rho;
+      acc += (double)(T(0.5) * (ux * ux + uy * uy + uz * uz));
+    } else {
+      acc += (double)rho;
+    }
+  }
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+static __global__ void __launch_bounds__(kThreads) finish_sum_kernel(const double *__restrict__ partial,
+                                                              int n, double *__restrict__ out) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += kThreads) acc += partial[i];
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) *out = s;
+}
+
+// node descriptor byte + sparse streaming-mask bits from the reference's two mask tensors
+static __global__ void __launch_bounds__(kThreads) compile_masks_kernel(
+    const unsigned char *__restrict__ ncm, const unsigned char *__restrict__ nsm, int q,
+    long long N, unsigned char *__restrict__ node, unsigned *__restrict__ bits) {
+  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= N) return;
+  unsigned b = 0;
+  if (nsm) {
+    for (int k = 1; k < q; ++k)
+      if (nsm[(long long)k * N + i] == 1) b |= 1u << k;
+  }
+  node[i] = (unsigned char)((ncm ? (ncm[i] & 0x7f) : 0) | (b ? 0x80 : 0));
+  if (bits) bits[i] = b;
+}
+
+}  // namespace lt
