@@ -1,0 +1,194 @@
+"""Headline benchmark: MLUPS of the LBM stream-and-collide hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json): TaylorGreenVortex3D, D3Q19, BGK, fp32, Re 1600, Ma 0.1, synthetic
+(analytic) initial condition incl. the f_neq initialisation.
+  N = 1   256^3 on one GPU (configs[1]) through lt.Simulation and the fused HIP kernel.
+  N > 1   weak scaling, 256^3 nodes per GPU, z-slab decomposition with RCCL ghost-plane
+          exchange: global 256 x 256 x 256N for N = 2, 4 and BASELINE's 512^3 for N = 8
+          (configs[2]: 512 x 512 x 64 per GPU).
+A "step" is one full lattice update (collide, stream) of every node.  The timed region is
+exactly K steps between barrier + device synchronise, max over ranks; value = all nodes of all
+ranks * K / time.  One JSON line is printed by rank 0.
+
+roofline: HBM-bound kernel.  achieved = algorithmic bytes per launch (2 * 19 * 4 = 152 B per
+node) / average duration of the fused stream-collide launches, measured with
+HIP events recorded on the launch stream around the K-1 fused launches of the timed region.
+cpu_baseline: the CPU oracle (a torch-CPU restatement of the reference's path, validated
+against the reference) timed on this box's host cores on the same 256^3 workload for a few
+steps (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s copy ceiling
+BYTES_PER_NODE = 2 * 19 * 4      # D3Q19 fp32: every population read once, written once
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=256, help="nodes per side of the per-GPU block")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="slab path: exchange without overlap")
+    return ap.parse_args()
+
+
+def cpu_baseline(size, steps):
+    """The oracle on the host cores, same workload, bounded sample."""
+    from oracle import lettuce_oracle as orc
+    threads = torch.get_num_threads()
+    sim = orc.taylor_green([size] * 3, 1600, 0.1, "D3Q19", torch.float32)
+    sim.step(1)                                   # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    sim.step(steps)
+    dt = time.perf_counter() - t0
+    return {"value": round(steps * size ** 3 / 1e6 / dt, 3), "unit": "MLUPS", "cores": threads,
+            "kind": "port",
+            "sample": f"oracle/lettuce_oracle.py (torch CPU ops), TGV3D D3Q19 BGK fp32 {size}^3, "
+                      f"{steps} steps after 1 warm-up step, {threads} threads"}
+
+
+def traffic_from_profile(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/traffic.json, produced by tools/pmc_traffic.py on the GPU box); null if absent."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            table = json.load(fh)
+        for row in table.get("kernels", []):
+            if row.get("workload") == "tgv3d_d3q19_bgk_f32_256" and row.get("hbm_bytes_per_launch"):
+                return row["hbm_bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import lettuce_amd as lt
+    ctx = lt.Context(device=device, dtype=torch.float32, use_native=True)
+    n = args.size
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def barrier():
+        if distributed:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(device)
+
+    if not distributed:
+        flow = lt.TaylorGreenVortex(ctx, [n, n, n], 1600, 0.1, lt.D3Q19())
+        sim = lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])
+        global_res = [n, n, n]
+        nodes_per_rank = n ** 3
+        kernel = sim._native.plan.kernel_name()
+        sim(args.warmup)
+        sim._native.fused_events = (start, end)
+        step = sim
+        parallelism = "single GPU"
+    else:
+        if world == 8 and n == 256:
+            global_res = [512, 512, 512]           # BASELINE configs[2]
+        else:
+            global_res = [n, n, n * world]
+        slab = lt.ZSlab(global_res)
+        flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 1600, 0.1, lt.D3Q19(), slab=slab)
+        sim = lt.SlabSimulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
+                                overlap=not args.no_overlap)
+        nodes_per_rank = global_res[0] * global_res[1] * slab.nz_local
+        kernel = sim.engine.kernel_name()
+        sim(args.warmup)
+        step = sim
+        parallelism = f"z-slab x{world}, RCCL send/recv ghost planes" + (
+            "" if not args.no_overlap else " (no overlap)")
+
+    barrier()
+    t0 = time.perf_counter()
+    step(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    total_nodes = nodes_per_rank * world
+    mlups = args.steps * total_nodes / 1e6 / elapsed
+
+    roofline = None
+    if not distributed and args.steps > 1:
+        fused_ms = start.elapsed_time(end) / (args.steps - 1)
+        achieved = BYTES_PER_NODE * nodes_per_rank / (fused_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic_from_profile(kernel),
+                    "kernel": kernel, "avg_launch_ms": round(fused_ms, 5),
+                    "algorithmic_bytes_per_launch": BYTES_PER_NODE * nodes_per_rank,
+                    "launches_timed": args.steps - 1}
+    elif distributed:
+        # per-rank fused-kernel rate is not separable from the exchange here; report the
+        # effective whole-step rate of one rank against the same algorithmic bytes
+        eff = BYTES_PER_NODE * nodes_per_rank * args.steps / elapsed / 1e9
+        roofline = {"bound": "hbm", "achieved": round(eff, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(eff / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
+                    "note": "whole-step effective rate per GPU (includes halo exchange and the "
+                            "collide/stream passes of the batch)"}
+
+    if rank == 0:
+        line = {
+            "metric": "MLUPS (million lattice updates/s), D3Q19 TGV, fused collide-stream",
+            "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"TaylorGreenVortex3D D3Q19 BGK fp32 "
+                                   f"{global_res[0]}x{global_res[1]}x{global_res[2]} "
+                                   f"({nodes_per_rank} nodes per GPU), Re=1600 Ma=0.1",
+                       "global_resolution": global_res, "parallelism": parallelism,
+                       "passes_per_batch": "1 collide + (K-1) fused stream-collide + 1 stream"},
+            "roofline": roofline,
+        }
+        if not distributed and not args.no_cpu_baseline:
+            del sim, flow
+            torch.cuda.empty_cache()
+            line["cpu_baseline"] = cpu_baseline(n, args.cpu_baseline_steps)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,250 @@
+"""Multi-GPU: 1-D slab decomposition along z, one process per GPU.
+
+The reference has no distributed code at all; this module is the
+build's addition, designed for MI355X nodes: RCCL point-to-point over xGMI, every rank talking
+to its two z-neighbours only.
+
+Layout.  A rank stores its slab as ``[q][nz_local + 2][ny][nx]`` (x fastest, z slowest --
+``LT_LAYOUT_SLAB`` of include/lettuce_hip.h) with one ghost plane below and above.  With z
+slowest a ghost plane of one population is a single contiguous ``ny*nx`` block, so the halo
+exchange sends straight out of and receives straight into the population buffers: no pack or
+unpack kernels and no staging copies.
+
+Schedule of one fused step (pull scheme, state = post-collision populations f*):
+  1. stream-collide the two boundary planes (1 and nz_local) -> they are what the neighbours need;
+  2. start the exchange of those planes on the communication stream: the populations with
+     e_z = -1 of plane 1 go to the lower neighbour's upper ghost plane, those with e_z = +1 of
+     plane nz_local to the upper neighbour's lower ghost plane (5 + 5 of 19 for D3Q19);
+  3. stream-collide the interior planes on the compute stream while the exchange is in flight
+     (interior nodes never read a ghost plane);
+  4. the compute stream waits for the exchange before the next step's boundary planes.
+There is no collective on the step path; only observables use an all-reduce.
+"""
+from timeit import default_timer as timer
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .util import LettuceException
+
+__all__ = ["ZSlab", "SlabSimulation"]
+
+
+class ZSlab:
+    """Which z-planes of the global grid this rank owns.
+
+    ``halo`` extra planes on both sides are carried only while the initial condition is built
+    (the 6th-order finite differences of the TGV f_neq initialisation reach 3 planes), see
+    ``extended_resolution`` and the ``slab=`` argument of the flows."""
+
+    def __init__(self, global_resolution: List[int], rank: Optional[int] = None,
+                 world_size: Optional[int] = None, halo: int = 3):
+        if len(global_resolution) != 3:
+            raise LettuceException("z-slab decomposition needs a 3-D grid")
+        if rank is None or world_size is None:
+            if dist.is_available() and dist.is_initialized():
+                rank, world_size = dist.get_rank(), dist.get_world_size()
+            else:
+                rank, world_size = 0, 1
+        nx, ny, nz = (int(n) for n in global_resolution)
+        if nz % world_size != 0:
+            raise LettuceException(f"nz = {nz} is not divisible by the {world_size} ranks")
+        self.global_resolution = [nx, ny, nz]
+        self.rank, self.world_size, self.halo = rank, world_size, halo
+        self.nz_local = nz // world_size
+        self.z_begin = rank * self.nz_local
+        self.prev = (rank - 1) % world_size
+        self.next = (rank + 1) % world_size
+
+    @property
+    def local_resolution(self):
+        nx, ny, _ = self.global_resolution
+        return [nx, ny, self.nz_local]
+
+    @property
+    def extended_resolution(self):
+        nx, ny, _ = self.global_resolution
+        return [nx, ny, self.nz_local + 2 * self.halo]
+
+    def z_indices(self, device=None):
+        """global z index of every plane of the extended slab (periodic)"""
+        nz = self.global_resolution[2]
+        return (torch.arange(-self.halo, self.nz_local + self.halo, device=device)
+                + self.z_begin) % nz
+
+
+def _crossing_sets(stencil):
+    e = np.array(stencil.e)
+    up = [int(q) for q in np.nonzero(e[:, 2] == 1)[0]]     # move to +z: fill the lower ghost
+    down = [int(q) for q in np.nonzero(e[:, 2] == -1)[0]]  # move to -z: fill the upper ghost
+    return up, down
+
+
+class SlabSimulation:
+    """Time-step driver of one rank's slab.
+
+    ``flow`` is a periodic flow built on ``slab.extended_resolution`` with ``slab=slab`` (so
+    that its initial condition equals the global one on this rank's planes); ``collision`` is a
+    BGK / KBC / NoCollision object.  ``engine`` defaults to the HIP engine; tests inject a
+    CPU stand-in with the same three ``*_planes`` methods to exercise the decomposition and the
+    exchange with the gloo backend.
+    """
+
+    def __init__(self, flow, collision, slab: ZSlab, reporter=None, engine=None, group=None,
+                 overlap: bool = True):
+        if flow.boundaries:
+            raise LettuceException("the slab driver handles periodic flows (no boundaries)")
+        if list(flow.resolution) != slab.extended_resolution:
+            raise LettuceException(f"flow resolution {flow.resolution} != extended slab "
+                                   f"{slab.extended_resolution}")
+        self.flow, self.collision, self.slab = flow, collision, slab
+        self.context = flow.context
+        self.reporter = reporter if reporter is not None else []
+        self.group = group
+        self.i = 0
+        self.overlap = overlap and self.context.device.type == "cuda"
+        nx, ny, _ = slab.global_resolution
+        nzl, h = slab.nz_local, slab.halo
+        self.nzl = nzl
+        self.up, self.down = _crossing_sets(flow.stencil)
+        desc = collision.native_generator()
+        self._tau = desc.tau
+        if engine is None:
+            from ._native import Plan, LAYOUT_SLAB
+            engine = Plan(type(flow.stencil).__name__, self.context.dtype, desc.kind,
+                          slab.local_resolution, layout=LAYOUT_SLAB, ghost_planes=1,
+                          device=self.context.device)
+        self.engine = engine
+        # [q, nx, ny, nzl + 2] incl. one ghost plane per side -> [q, nzl + 2, ny, nx]
+        core = flow.f[..., h - 1:h + nzl + 1]
+        self.f = core.permute(0, 3, 2, 1).contiguous()
+        self.f_next = torch.empty_like(self.f)
+        flow.f = None                       # the extended slab is not needed any more
+        flow._f_next = None
+        self._comm = torch.cuda.Stream(device=self.context.device) if self.overlap else None
+
+    # ---- views ---------------------------------------------------------------------------------
+    def local_f(self) -> torch.Tensor:
+        """this rank's populations as a ``[q, nx, ny, nz_local]`` view (reference axis order)"""
+        return self.f[:, 1:self.nzl + 1].permute(0, 3, 2, 1)
+
+    def gather_f(self, dst: int = 0) -> Optional[torch.Tensor]:
+        """global ``[q, nx, ny, nz]`` tensor on rank ``dst`` (small grids / tests only)"""
+        local = self.local_f().contiguous()
+        if self.slab.world_size == 1:
+            return local
+        parts = ([torch.empty_like(local) for _ in range(self.slab.world_size)]
+                 if self.slab.rank == dst else None)
+        if dist.get_backend(self.group) == "nccl":
+            full = [torch.empty_like(local) for _ in range(self.slab.world_size)]
+            dist.all_gather(full, local, group=self.group)
+            parts = full if self.slab.rank == dst else None
+        else:
+            dist.gather(local, parts, dst=dst, group=self.group)
+        return torch.cat(parts, dim=3) if parts is not None else None
+
+    # ---- halo exchange -------------------------------------------------------------------------
+    def _exchange(self, buf: torch.Tensor):
+        """Fill the ghost planes of ``buf`` (post-collision populations) from the neighbours.
+        Returns the outstanding requests (empty when done synchronously)."""
+        nzl, s = self.nzl, self.slab
+        if s.world_size == 1:
+            buf[self.down, nzl + 1] = buf[self.down, 1]
+            buf[self.up, 0] = buf[self.up, nzl]
+            return []
+        ops = []
+        for q in self.down:     # towards -z: my plane 1 -> prev's upper ghost
+            ops.append(dist.P2POp(dist.isend, buf[q, 1], s.prev, self.group, tag=q))
+            ops.append(dist.P2POp(dist.irecv, buf[q, nzl + 1], s.next, self.group, tag=q))
+        for q in self.up:       # towards +z: my top plane -> next's lower ghost
+            ops.append(dist.P2POp(dist.isend, buf[q, nzl], s.next, self.group, tag=100 + q))
+            ops.append(dist.P2POp(dist.irecv, buf[q, 0], s.prev, self.group, tag=100 + q))
+        return dist.batch_isend_irecv(ops)
+
+    @staticmethod
+    def _wait(reqs):
+        for r in reqs:
+            r.wait()
+
+    # ---- stepping --------------------------------------------------------------------------------
+    def _fused_step(self, cur, nxt, tau):
+        eng, nzl = self.engine, self.nzl
+        eng.stream_collide_planes(cur, nxt, tau, 1, 2)
+        if nzl > 1:
+            eng.stream_collide_planes(cur, nxt, tau, nzl, nzl + 1)
+        if self.overlap:
+            compute = torch.cuda.current_stream()
+            self._comm.wait_stream(compute)
+            with torch.cuda.stream(self._comm):
+                reqs = self._exchange(nxt)
+                self._wait(reqs)              # orders the comm stream behind the transfers
+            if nzl > 2:
+                eng.stream_collide_planes(cur, nxt, tau, 2, nzl)   # overlaps with the exchange
+            compute.wait_stream(self._comm)
+        else:
+            reqs = self._exchange(nxt)
+            if nzl > 2:
+                eng.stream_collide_planes(cur, nxt, tau, 2, nzl)
+            self._wait(reqs)
+
+    def _advance(self, n: int):
+        """n whole steps: collide, exchange, (n-1) x fused, stream -- as lt_run does on one GPU."""
+        tau = float(self._tau(self.flow))
+        eng, nzl = self.engine, self.nzl
+        cur, nxt = self.f, self.f_next
+        eng.collide_planes(cur, nxt, tau, 1, nzl + 1)
+        cur, nxt = nxt, cur
+        self._wait(self._exchange(cur))
+        for _ in range(n - 1):
+            self._fused_step(cur, nxt, tau)
+            cur, nxt = nxt, cur
+        eng.stream_planes(cur, nxt, 1, nzl + 1)
+        self.f, self.f_next = nxt, cur
+
+    def _next_report(self, limit):
+        k = limit
+        for r in self.reporter:
+            interval = getattr(r, "interval", None)
+            if not isinstance(interval, (int, np.integer)) or interval < 1:
+                return 1
+            k = min(k, interval - self.i % interval)
+        return max(1, k)
+
+    def __call__(self, num_steps: int) -> float:
+        """Advance; returns this rank's MLUPS (local nodes only)."""
+        beg = timer()
+        if self.i == 0:
+            for r in self.reporter:
+                r(self)
+        remaining = int(num_steps)
+        while remaining > 0:
+            k = self._next_report(remaining)
+            self._advance(k)
+            self.i += k
+            remaining -= k
+            for r in self.reporter:
+                r(self)
+        if self.context.device.type == "cuda":
+            torch.cuda.synchronize(self.context.device)
+        nx, ny, _ = self.slab.global_resolution
+        return num_steps * nx * ny * self.nzl / 1e6 / (timer() - beg)
+
+    # ---- observables -----------------------------------------------------------------------------
+    def kinetic_energy_pu(self) -> float:
+        """IncompressibleKineticEnergy of the whole domain (all-reduced over the ranks)."""
+        flow, units = self.flow, self.flow.units
+        if hasattr(self.engine, "kinetic_energy_lu"):
+            total = self.engine.kinetic_energy_lu(self.f)
+        else:
+            f = self.local_f()
+            rho = torch.sum(f, dim=0)
+            j = torch.einsum("qd,q...->d...", flow.torch_stencil.e, f)
+            u = j / rho
+            total = torch.sum(0.5 * torch.einsum("d...,d...->...", u, u)).double()
+        if self.slab.world_size > 1:
+            total = total.clone()
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+        dx = units.convert_length_to_pu(1.0)
+        return float(units.convert_incompressible_energy_to_pu(total) * dx ** 3)

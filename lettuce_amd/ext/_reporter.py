@@ -1,0 +1,107 @@
+"""Observables read between steps ("next" row F3) and the reporter that logs them.
+
+API of lettuce/ext/_reporter/observable_reporter.py:17-42,140-199.  On a native context the
+kinetic energy and the mass are device-side wavefront/LDS reductions in fp64
+(``lt_kinetic_energy`` / ``lt_mass``) -- no [d, *res] velocity field is materialised.
+VTK / HDF5 / image writers, the energy spectrum and the error reporter are host-side
+post-processing and out of scope.
+"""
+import sys
+from abc import ABC, abstractmethod
+from typing import Optional
+
+import torch
+
+from .._simulation import Reporter
+from ..util import torch_gradient
+
+__all__ = ["Observable", "ObservableReporter", "MaximumVelocity", "IncompressibleKineticEnergy",
+           "Enstrophy", "Mass"]
+
+
+class Observable(ABC):
+    def __init__(self, flow: "Flow"):
+        self.context = flow.context
+        self.flow = flow
+
+    @abstractmethod
+    def __call__(self, f: Optional[torch.Tensor] = None):
+        ...
+
+
+class MaximumVelocity(Observable):
+    def __call__(self, f: Optional[torch.Tensor] = None):
+        return torch.norm(self.flow.u_pu, dim=0).max()
+
+
+class IncompressibleKineticEnergy(Observable):
+    """E_pu = sum_x 0.5 u_lu.u_lu * (u_char_pu / u_char_lu)^2 * dx_pu^d  -- the parity metric of
+    the north star (lettuce/ext/_reporter/observable_reporter.py:34-42)."""
+
+    def __call__(self, f: Optional[torch.Tensor] = None):
+        flow = self.flow
+        dx = flow.units.convert_length_to_pu(1.0)
+        plan = flow._engine_plan(flow.f)
+        if plan is not None:
+            total = plan.kinetic_energy_lu(flow.f)      # fp64 device scalar
+        else:
+            total = torch.sum(flow.incompressible_energy())
+        kin = flow.units.convert_incompressible_energy_to_pu(total)
+        kin *= dx ** flow.stencil.d
+        return kin
+
+
+class Enstrophy(Observable):
+    """Integral of the squared vorticity; periodic domains only
+    (observable_reporter.py:45-68)."""
+
+    def __call__(self, f: Optional[torch.Tensor] = None):
+        flow = self.flow
+        dx = flow.units.convert_length_to_pu(1.0)
+        u = flow.units.convert_velocity_to_pu(flow.u())
+        grad = [torch_gradient(u[a], dx=dx, order=6) for a in range(flow.stencil.d)]
+        w_z = grad[0][1] - grad[1][0]
+        total = torch.sum(w_z * w_z)
+        if flow.stencil.d == 3:
+            w_x = grad[2][1] - grad[1][2]
+            w_y = grad[0][2] - grad[2][0]
+            total += torch.sum(w_x * w_x + w_y * w_y)
+        return total * dx ** flow.stencil.d
+
+
+class Mass(Observable):
+    """Total mass in lattice units (observable_reporter.py:140-158)."""
+
+    def __init__(self, flow: "Flow", no_mass_mask=None):
+        super().__init__(flow)
+        self.mask = no_mass_mask
+
+    def __call__(self, f: Optional[torch.Tensor] = None):
+        mass = f[..., 1:-1, 1:-1].sum()
+        if self.mask is not None:
+            mass -= (f * self.mask.to(dtype=torch.float)).sum()
+        return mass
+
+
+class ObservableReporter(Reporter):
+    """Evaluates ``observable`` every ``interval`` steps and prints ``i t_pu value...`` or
+    appends it to ``out`` when that is a list (observable_reporter.py:161-199)."""
+
+    def __init__(self, observable, interval=1, out=sys.stdout):
+        super().__init__(interval)
+        self.observable = observable
+        self.out = [] if out is None else out
+        self._parameter_name = type(observable).__name__
+        print("steps    ", "time    ", self._parameter_name)
+
+    def __call__(self, simulation: "Simulation"):
+        if simulation.flow.i % self.interval != 0:
+            return
+        observed = self.observable.context.convert_to_ndarray(self.observable(simulation.flow.f))
+        assert len(observed.shape) < 2
+        values = [observed.item()] if observed.ndim == 0 else observed.tolist()
+        entry = [simulation.flow.i, simulation.units.convert_time_to_pu(simulation.flow.i)] + values
+        if isinstance(self.out, list):
+            self.out.append(entry)
+        else:
+            print(*entry, file=self.out)

@@ -1,0 +1,259 @@
+"""GPU tests through the lettuce-style Python API with the HIP engine in the swap point --
+the reference's tests/native/* restated: the same flow is stepped by the CPU oracle and by
+``Simulation`` on a native context, and the populations must agree."""
+import io
+from copy import copy
+
+import numpy as np
+import pytest
+import torch
+
+import lettuce_amd as lt
+from conftest import golden, unpack_nsm, TORCH_DT
+from oracle import lettuce_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu(dt="f32"):
+    return lt.Context(device="cuda:0", dtype=TORCH_DT[dt], use_native=True)
+
+
+class Dummy(lt.ExtFlow):
+    """16x16 D2Q9 flow with hand-set populations (tests/conftest.py:243-266 of the reference)."""
+
+    def __init__(self, context, fill, boundaries=None, resolution=16):
+        self._fill, self._b = fill, boundaries
+        lt.ExtFlow.__init__(self, context, resolution, 1.0, 1.0)
+
+    def make_resolution(self, resolution, stencil=None):
+        return [resolution, resolution] if isinstance(resolution, int) else resolution
+
+    def make_units(self, reynolds_number, mach_number, _):
+        return lt.UnitConversion(reynolds_number=reynolds_number, mach_number=mach_number)
+
+    def initial_pu(self):
+        ...
+
+    def initialize(self):
+        self._fill(self.f)
+
+    @property
+    def boundaries(self):
+        return [] if self._b is None else self._b(self)
+
+
+def test_default_context_on_gpu_box_is_native():
+    c = lt.Context()
+    assert c.device.type == "cuda" and c.use_native and c.dtype == torch.float32
+
+
+def test_native_streaming():
+    def tagged(f):
+        f.zero_()
+        for q in range(9):
+            f[q, q + 1, q + 1] = q + 1.0
+    flow = Dummy(gpu(), tagged)
+    sim = lt.Simulation(flow, lt.NoCollision(), [])
+    assert sim._native is not None
+    g = golden("native_streaming_d2q9_f32")
+    np.testing.assert_array_equal(flow.f.cpu().numpy(), g["f0"])
+    sim(1)
+    np.testing.assert_array_equal(flow.f.cpu().numpy(), g["f1"])
+
+
+def test_native_bgk_collision():
+    def bump(f):
+        f[:, :, :] = 1.0
+        f[:, 2, 2] = 2.0
+    flow = Dummy(gpu(), bump)
+    lt.Simulation(flow, lt.BGKCollision(2.0), [])(1)
+    assert flow.f.cpu().numpy() == pytest.approx(golden("native_bgk_d2q9_f32")["f1"])   # rel 1e-6
+
+
+def test_native_bounce_back():
+    class Box(lt.BounceBackBoundary):
+        def make_no_collision_mask(self, shape, context):
+            m = context.zero_tensor(shape, dtype=bool)
+            m[0, :] = True; m[:, 0] = True; m[2:, :] = True; m[:, 2:] = True
+            return m
+
+    def one_node(f):
+        f.zero_()
+        f[:, 1, 1] = 1.0
+    flow = Dummy(gpu(), one_node, lambda fl: [Box(torch.ones(fl.resolution))])
+    sim = lt.Simulation(flow, lt.NoCollision(), [])
+    g = golden("native_bounce_back_d2q9_f32")
+    sim(1)
+    np.testing.assert_array_equal(flow.f.cpu().numpy(), g["f1"])
+    sim(1)
+    np.testing.assert_array_equal(flow.f.cpu().numpy(), g["f2"])
+
+
+def test_native_equilibrium_pu_with_tensor_arguments():
+    class Column(lt.EquilibriumBoundaryPU):
+        def make_no_collision_mask(self, shape, context):
+            a = context.zero_tensor(shape, dtype=bool)
+            a[:, 1] = True
+            return a
+
+        def make_no_streaming_mask(self, shape, context):
+            return context.one_tensor(shape, dtype=bool)
+    c = gpu("f64")
+
+    class TGVb(lt.TaylorGreenVortex):
+        extra = None
+
+        @property
+        def boundaries(self):
+            return [] if self.extra is None else [self.extra]
+    flow = TGVb(c, [16, 16], 1, 0.1)
+    flow.extra = Column(c, mask=None, velocity=np.ones([2, 16, 16]), pressure=np.ones([16, 16]))
+    g = golden("native_equilibrium_pu_d2q9_f64")
+    np.testing.assert_allclose(flow.f.cpu().numpy(), g["f0"], rtol=0, atol=1e-14)
+    lt.Simulation(flow, lt.NoCollision(), [])(1)
+    np.testing.assert_allclose(flow.f.cpu().numpy(), g["f1"], rtol=1e-6, atol=1e-14)
+
+
+def test_native_no_streaming_mask_assigned_after_construction():
+    class Uniform(lt.ExtFlow):
+        def make_resolution(self, resolution, stencil=None):
+            return [resolution] * stencil.d
+
+        def make_units(self, re, ma, resolution):
+            return lt.UnitConversion(re, ma, characteristic_length_lu=resolution[0])
+
+        def initial_pu(self):
+            return (0.01 * np.ones([1] + self.resolution), 1.01 * np.ones([2] + self.resolution))
+
+        @property
+        def boundaries(self):
+            return []
+    c = gpu()
+    flow = Uniform(c, 16, 1, 0.01, lt.D2Q9())
+    sim = lt.Simulation(flow, lt.NoCollision(), [])
+    sim.no_streaming_mask = c.zero_tensor(flow.resolution, dtype=bool)
+    f0 = copy(flow.f)
+    sim(64)
+    assert torch.isclose(f0, flow.f).all()
+    np.testing.assert_allclose(flow.f.cpu().numpy(), golden("native_no_streaming_mask_d2q9_f32")["f64"],
+                               rtol=1e-6)
+
+
+@pytest.mark.parametrize("name,stencil,coll,dt,n", [
+    ("tgv3d_d3q19_bgk_16_f64", lt.D3Q19, "bgk", "f64", 100), ("tgv3d_d3q19_bgk_16_f32", lt.D3Q19, "bgk", "f32", 10),
+    ("tgv3d_d3q27_kbc_16_f64", lt.D3Q27, "kbc", "f64", 50), ("tgv2d_d2q9_bgk_32_f64", lt.D2Q9, "bgk", "f64", 100)])
+def test_taylor_green_with_reporter_batches(name, stencil, coll, dt, n):
+    """Device-side TGV initialisation (F1) + batched stepping between reporter calls + the
+    fp64 wave-reduced kinetic energy (F3) against the reference's decay series."""
+    g = golden(name)
+    res = [int(r) for r in g["resolution"]]
+    flow = lt.TaylorGreenVortex(gpu(dt), res, float(g["reynolds"]), float(g["mach"]), stencil())
+    tol = 1e-13 if dt == "f64" else 2e-6
+    np.testing.assert_allclose(flow.f.cpu().numpy(), g["f0"], rtol=0, atol=tol)
+    collision = lt.BGKCollision(flow.units.relaxation_parameter_lu) if coll == "bgk" else lt.KBCCollision()
+    out = []
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setattr("sys.stdout", io.StringIO())
+        rep = lt.ObservableReporter(lt.IncompressibleKineticEnergy(flow), interval=10, out=out)
+    sim = lt.Simulation(flow, collision, [rep])
+    sim(n)
+    steps = [row[0] for row in out]
+    assert steps == list(range(0, n + 1, 10))
+    ref = dict(zip(g["energy_steps"].tolist(), g["energy_pu"].tolist()))
+    for i, _, e in out:
+        assert e == pytest.approx(ref[i], rel=1e-6)          # north star: KE decay to 1e-6 relative
+    atol = (1e-12 if dt == "f64" else 1e-5) * float(np.abs(g[f"f{n}"]).max())
+    np.testing.assert_allclose(flow.f.cpu().numpy(), g[f"f{n}"], rtol=0, atol=atol)
+
+
+@pytest.mark.parametrize("name,stencil,coll,dt", [("obstacle2d_d2q9_bgk_f64", lt.D2Q9, "bgk", "f64"),
+                                                   ("obstacle3d_d3q27_kbc_f32", lt.D3Q27, "kbc", "f32"),
+                                                   ("obstacle3d_d3q27_kbc_f64", lt.D3Q27, "kbc", "f64")])
+def test_obstacle_flow_end_to_end(name, stencil, coll, dt):
+    """BASELINE cfg4 physics: Obstacle wires inlet + ABB outlet + bounce-back; the reference's
+    own native path cannot run this flow at all."""
+    g = golden(name)
+    res = [int(r) for r in g["resolution"]]
+    flow = lt.Obstacle(gpu(dt), res, 100, 0.1, float(g["domain_length_x"]), stencil=stencil())
+    flow.mask = g["obstacle_mask"]
+    flow.initialize()
+    collision = lt.BGKCollision(flow.units.relaxation_parameter_lu) if coll == "bgk" else lt.KBCCollision()
+    sim = lt.Simulation(flow, collision, [])
+    np.testing.assert_array_equal(sim.no_collision_mask.cpu().numpy(), g["no_collision_mask"])
+    np.testing.assert_array_equal(sim.no_streaming_mask.cpu().numpy(), unpack_nsm(g))
+    sim(2)
+    atol = (1e-11 if dt == "f64" else 1e-5) * float(np.abs(g["f2"]).max())
+    np.testing.assert_allclose(flow.f.cpu().numpy(), g["f2"], rtol=0, atol=atol)
+    sim(6)
+    np.testing.assert_allclose(flow.f.cpu().numpy(), g["f8"], rtol=0, atol=atol)
+
+
+def test_flow_modified_between_calls_restarts_from_f():
+    """In-place edits of flow.f between calls must be honoured (the engine may otherwise carry
+    on from its post-collision buffer)."""
+    c = gpu("f64")
+    flow = lt.TaylorGreenVortex(c, [16, 16], 100, 0.05, lt.D2Q9())
+    sim = lt.Simulation(flow, lt.BGKCollision(0.7), [])
+    ref = orc.taylor_green([16, 16], 100, 0.05, "D2Q9", torch.float64)
+    ref.tau = 0.7
+    sim(3); ref.step(3)
+    sim(2); ref.step(2)                      # continues from f*
+    np.testing.assert_allclose(flow.f.cpu().numpy(), ref.f.numpy(), rtol=0, atol=1e-13)
+    flow.f[3] *= 1.01; ref.f[3] *= 1.01     # in-place edit
+    sim(2); ref.step(2)
+    np.testing.assert_allclose(flow.f.cpu().numpy(), ref.f.numpy(), rtol=0, atol=1e-13)
+    flow.f = flow.f.clone() * 0.99; ref.f = ref.f * 0.99      # re-assignment
+    sim(1); ref.step(1)
+    np.testing.assert_allclose(flow.f.cpu().numpy(), ref.f.numpy(), rtol=0, atol=1e-13)
+
+
+def test_collision_callable_and_moments_use_engine():
+    g = golden("operators_d3q27_f32")
+    flow = lt.TaylorGreenVortex(gpu(), list(g["f"].shape[1:]), 50, 0.1, lt.D3Q27())
+    flow.f = torch.tensor(g["f"], device="cuda")
+    np.testing.assert_allclose(flow.rho().cpu().numpy(), g["rho"], rtol=2e-6)
+    np.testing.assert_allclose(flow.u().cpu().numpy(), g["u"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(lt.BGKCollision(float(g["tau"]))(flow).cpu().numpy(), g["bgk"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(lt.KBCCollision()(flow).cpu().numpy(), g["kbc"], rtol=0, atol=4e-6)
+    np.testing.assert_allclose(flow.equilibrium(flow).cpu().numpy(), g["feq"], rtol=0, atol=2e-6)
+    assert flow._moment_plan is not None
+
+
+def test_unsupported_component_raises_on_native_context():
+    class MyCollision(lt.Collision):
+        def __call__(self, flow):
+            return flow.f
+
+        def native_available(self):
+            return False
+
+        def native_generator(self):
+            return None
+    flow = lt.TaylorGreenVortex(gpu(), [8, 8], 10, 0.05, lt.D2Q9())
+    with pytest.raises(lt.LettuceException, match="MyCollision"):
+        lt.Simulation(flow, MyCollision(), [])
+
+
+def test_slab_driver_single_rank_on_gpu():
+    """z-slab layout kernels + ghost-plane self exchange on one GPU == single-domain engine."""
+    res = [32, 16, 24]
+    c = gpu("f64")
+    slab = lt.ZSlab(res, rank=0, world_size=1)
+    flow = lt.TaylorGreenVortex(c, slab.extended_resolution, 400, 0.1, lt.D3Q19(), slab=slab)
+    tau = flow.units.relaxation_parameter_lu
+    sim = lt.SlabSimulation(flow, lt.BGKCollision(tau), slab)
+    ref = orc.taylor_green(res, 400, 0.1, "D3Q19", torch.float64)
+    np.testing.assert_allclose(sim.gather_f().cpu().numpy(), ref.f.numpy(), rtol=0, atol=1e-14)
+    sim(4); sim(3)
+    ref.step(7)
+    np.testing.assert_allclose(sim.gather_f().cpu().numpy(), ref.f.numpy(), rtol=0, atol=1e-13)
+    assert sim.kinetic_energy_pu() == pytest.approx(float(orc.kinetic_energy_pu(ref.f, ref.lat, ref.units)), rel=1e-11)
+    # D3Q27 KBC fp32 through the slab kernels, wide (x % 4 == 0) and narrow paths
+    for rs in ([16, 8, 6], [10, 6, 4]):
+        slab = lt.ZSlab(rs, rank=0, world_size=1)
+        flow = lt.TaylorGreenVortex(gpu(), slab.extended_resolution, 400, 0.1, lt.D3Q27(), slab=slab)
+        sim = lt.SlabSimulation(flow, lt.KBCCollision(), slab)
+        ref = orc.taylor_green(rs, 400, 0.1, "D3Q27", torch.float32, "kbc")
+        sim(5); ref.step(5)
+        np.testing.assert_allclose(sim.gather_f().cpu().numpy(), ref.f.numpy(), rtol=0, atol=2e-6)

@@ -1,0 +1,288 @@
+"""Host-side mirror of the reference interface (CPU, no GPU needed): the non-native mode of
+lettuce_amd must give the reference's results (golden vectors), keep its invariants
+(tests/collision/*, tests/stencil/*, tests/boundary/* of the reference) and its API contract
+(SURVEY.md Appendix C)."""
+import io
+import os
+import re
+from copy import copy
+
+import numpy as np
+import pytest
+import torch
+
+import lettuce_amd as lt
+from conftest import golden, unpack_nsm, TORCH_DT, ROOT
+
+STENCILS = [lt.D1Q3, lt.D2Q9, lt.D3Q15, lt.D3Q19, lt.D3Q27]
+
+
+def ctx(dt="f64"):
+    return lt.Context("cpu", TORCH_DT[dt], use_native=False)
+
+
+class UniformFlow(lt.ExtFlow):
+    """The reference's TestFlow (tests/conftest.py:195-232): u = 1.01, p = 0.01 everywhere."""
+
+    def __init__(self, context, resolution, reynolds_number, mach_number, stencil=None, equilibrium=None):
+        self._boundaries = []
+        super().__init__(context, resolution, reynolds_number, mach_number, stencil, equilibrium)
+
+    def make_resolution(self, resolution, stencil=None):
+        if isinstance(resolution, int):
+            return [resolution] if stencil is None else [resolution] * stencil.d
+        return resolution
+
+    def make_units(self, reynolds_number, mach_number, resolution):
+        return lt.UnitConversion(reynolds_number, mach_number, characteristic_length_lu=resolution[0])
+
+    def initial_pu(self):
+        return (0.01 * np.ones([1] + self.resolution), 1.01 * np.ones([self.stencil.d] + self.resolution))
+
+    @property
+    def boundaries(self):
+        return self._boundaries
+
+    @boundaries.setter
+    def boundaries(self, b):
+        self._boundaries = b
+
+
+# ------------------------------------------------------------------ stencils (tests/stencil/*)
+@pytest.mark.parametrize("cls", STENCILS, ids=[c.__name__ for c in STENCILS])
+def test_stencil_properties_and_tables(cls):
+    from oracle import lettuce_oracle as orc
+    s = cls()
+    e, w = np.array(s.e), np.array(s.w)
+    assert w.sum() == pytest.approx(1.0)
+    assert (e.sum(axis=0) == 0).all() and (e[0] == 0).all()
+    assert (e[s.opposite] == -e).all()
+    assert s.cs == 1 / np.sqrt(3.0)
+    ref = orc.LATTICES[cls.__name__]
+    assert [list(v) for v in ref.e] == s.e and list(ref.opposite) == s.opposite
+    assert list(ref.w) == pytest.approx(s.w, rel=1e-16)
+    assert (s.d, s.q) == (ref.d, ref.q)
+
+
+def test_csrc_lattice_tables_match_python():
+    """lettuce_amd/csrc/lattice.hpp holds the same velocity order as the Python stencils."""
+    text = open(os.path.join(ROOT, "lettuce_amd", "csrc", "lattice.hpp")).read()
+    for cls in (lt.D2Q9, lt.D3Q19, lt.D3Q27):
+        s = cls()
+        block = text.split(f"struct {cls.__name__} ")[1].split("static constexpr double W")[0]
+        nums = [int(v) for v in re.findall(r"-?\d+", block.split("E[")[1].split("=", 1)[1])]
+        table = np.array(nums).reshape(s.q, 3)[:, :s.d]
+        assert table.tolist() == s.e
+        opp = text.split(f"struct {cls.__name__} ")[1].split("OPP[")[1].split("=", 1)[1].split("}")[0]
+        assert [int(v) for v in re.findall(r"\d+", opp)] == s.opposite
+
+
+# ------------------------------------------------------------------ golden vectors, non-native
+TGV = [("tgv2d_d2q9_bgk_32_f64", lt.D2Q9, "bgk", "f64", 10), ("tgv3d_d3q19_bgk_16_f32", lt.D3Q19, "bgk", "f32", 10),
+       ("tgv3d_d3q27_kbc_16_f64", lt.D3Q27, "kbc", "f64", 10), ("tgv3d_d3q19_bgk_ragged_f64", lt.D3Q19, "bgk", "f64", 7)]
+
+
+@pytest.mark.parametrize("name,stencil,coll,dt,n", TGV, ids=[t[0] for t in TGV])
+def test_taylor_green_matches_reference(name, stencil, coll, dt, n):
+    g = golden(name)
+    res = [int(r) for r in g["resolution"]]
+    flow = lt.TaylorGreenVortex(ctx(dt), res, float(g["reynolds"]), float(g["mach"]), stencil())
+    tol = 2e-14 if dt == "f64" else 2e-6
+    np.testing.assert_allclose(flow.f.numpy(), g["f0"], rtol=0, atol=tol)
+    collision = lt.BGKCollision(flow.units.relaxation_parameter_lu) if coll == "bgk" else lt.KBCCollision(tau=0.9)
+    out = []
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setattr("sys.stdout", io.StringIO())
+        rep = lt.ObservableReporter(lt.IncompressibleKineticEnergy(flow), interval=n, out=out)
+    sim = lt.Simulation(flow, collision, [rep])
+    mlups = sim(n)
+    assert mlups > 0 and flow.i == n
+    np.testing.assert_allclose(flow.f.numpy(), g[f"f{n}"], rtol=0, atol=tol * 5)
+    assert [row[0] for row in out] == [0, n]
+    ref = dict(zip(g["energy_steps"].tolist(), g["energy_pu"].tolist()))
+    assert out[0][2] == pytest.approx(ref[0], rel=1e-12 if dt == "f64" else 2e-6)
+    assert out[1][2] == pytest.approx(ref[n], rel=1e-12 if dt == "f64" else 2e-6)
+    if coll == "kbc":    # the constructor's tau is ignored (kbc_collision.py:97-99)
+        assert collision.tau == flow.units.relaxation_parameter_lu
+
+
+@pytest.mark.parametrize("name,stencil,coll", [("obstacle2d_d2q9_bgk_f64", lt.D2Q9, "bgk"),
+                                                ("obstacle3d_d3q27_kbc_f64", lt.D3Q27, "kbc")])
+def test_obstacle_flow_matches_reference(name, stencil, coll):
+    g = golden(name)
+    res = [int(r) for r in g["resolution"]]
+    flow = lt.Obstacle(ctx(), res, 100, 0.1, float(g["domain_length_x"]), stencil=stencil())
+    flow.mask = g["obstacle_mask"]
+    flow.initialize()
+    np.testing.assert_allclose(flow.f.numpy(), g["f0"], rtol=0, atol=1e-15)
+    collision = lt.BGKCollision(flow.units.relaxation_parameter_lu) if coll == "bgk" else lt.KBCCollision()
+    sim = lt.Simulation(flow, collision, [])
+    assert [type(b).__name__ for b in sim.boundaries[1:]] == list(g["boundary_order"])
+    np.testing.assert_array_equal(sim.no_collision_mask.numpy(), g["no_collision_mask"])
+    np.testing.assert_array_equal(sim.no_streaming_mask.numpy(), unpack_nsm(g))
+    sim(2)
+    np.testing.assert_allclose(flow.f.numpy(), g["f2"], rtol=0, atol=1e-13)
+
+
+def test_shear_flows():
+    flow2 = lt.DoublyPeriodicShear2D(ctx(), 16, 100, 0.05)
+    assert float(flow2.initial_pu()[1][0].min()) == 1.0          # the reference's swapped branches
+    g = golden("shear3d_d3q19_bgk_f64")
+    flow = lt.DoublyPeriodicShear3D(ctx(), 16, 1000, 0.1)
+    np.testing.assert_allclose(flow.f.numpy(), g["f0"], rtol=0, atol=1e-14)
+    lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])(5)
+    np.testing.assert_allclose(flow.f.numpy(), g["f5"], rtol=0, atol=1e-13)
+
+
+# ------------------------------------------------------------------ invariants (tests/collision/*)
+@pytest.mark.parametrize("cls", STENCILS, ids=[c.__name__ for c in STENCILS])
+@pytest.mark.parametrize("collision", ["bgk", "kbc"])
+def test_collision_conserves_mass_and_momentum(cls, collision):
+    s = cls()
+    if collision == "kbc" and cls not in (lt.D2Q9, lt.D3Q27):
+        pytest.skip("KBC exists for D2Q9 / D3Q27")
+    flow = UniformFlow(ctx(), [16] * s.d, 1, 0.01, s)
+    torch.manual_seed(1)
+    flow.f = flow.f * (1 + 0.05 * torch.rand_like(flow.f))
+    coll = lt.BGKCollision(0.51) if collision == "bgk" else lt.KBCCollision(0.51)
+    rho0, j0 = flow.rho(), flow.j()
+    flow.f = coll(flow)
+    assert torch.allclose(flow.rho(), rho0, atol=1e-12)
+    assert torch.allclose(flow.j(), j0, atol=1e-12)
+
+
+def test_bgk_fixpoint_two_applications_at_tau_half():
+    flow = UniformFlow(ctx(), [16, 16], 1, 0.01, lt.D2Q9())
+    torch.manual_seed(2)
+    flow.f = torch.rand_like(flow.f) + 1
+    f0 = copy(flow.f)
+    coll = lt.BGKCollision(0.5)
+    flow.f = coll(flow)
+    flow.f = coll(flow)
+    assert torch.allclose(flow.f, f0, atol=1e-12)
+
+
+def test_equilibrium_moments():
+    flow = UniformFlow(ctx(), [8, 8, 8], 1, 0.01, lt.D3Q27())
+    feq = flow.equilibrium(flow)
+    assert torch.allclose(flow.rho(feq), flow.rho(), atol=1e-13)
+    assert torch.allclose(flow.j(feq), flow.j(), atol=1e-13)
+
+
+def test_bounce_back_and_abb_masks():
+    flow = UniformFlow(ctx(), [8, 6, 4], 1, 0.01, lt.D3Q19())
+    f_old = copy(flow.f)
+    out = lt.BounceBackBoundary(torch.ones(flow.resolution, dtype=torch.bool))(flow)
+    assert torch.equal(out, f_old[flow.stencil.opposite])
+    abb = lt.AntiBounceBackOutlet([0, -1, 0], flow)
+    ncm = abb.make_no_collision_mask(flow.resolution, flow.context)
+    nsm = abb.make_no_streaming_mask([19] + flow.resolution, flow.context)
+    assert ncm[:, 0, :].all() and not ncm[:, 1:, :].any()
+    moving_in = [q for q in range(19) if flow.stencil.e[q][1] == 1]
+    assert nsm[moving_in][:, :, 0, :].all() and int(nsm.sum()) == len(moving_in) * 8 * 4
+    with pytest.raises(AssertionError):
+        lt.AntiBounceBackOutlet([1, 1, 0], flow)
+
+
+# ------------------------------------------------------------------ API contract
+def test_public_namespace_and_signatures():
+    for name in ["Context", "Stencil", "TorchStencil", "UnitConversion", "Flow", "Equilibrium", "Boundary",
+                 "Collision", "Reporter", "Simulation", "ExtFlow", "TaylorGreenVortex", "TaylorGreenVortex2D",
+                 "TaylorGreenVortex3D", "Obstacle", "DoublyPeriodicShear2D", "QuadraticEquilibrium",
+                 "BGKCollision", "KBCCollision", "KBCCollision2D", "KBCCollision3D", "NoCollision",
+                 "BounceBackBoundary", "EquilibriumBoundaryPU", "AntiBounceBackOutlet", "Observable",
+                 "ObservableReporter", "IncompressibleKineticEnergy", "MaximumVelocity", "Mass", "Enstrophy",
+                 "LettuceException", "torch_gradient", "append_axes", "D1Q3", "D2Q9", "D3Q15", "D3Q19", "D3Q27"]:
+        assert hasattr(lt, name), name
+    c = lt.Context("cpu")
+    assert c.dtype == torch.float32 and c.use_native is False
+    with pytest.raises(AssertionError):
+        lt.Context("cpu", use_native=True)
+    assert lt.Context("cpu").convert_to_tensor(np.array([True])).dtype == torch.bool
+    u = lt.UnitConversion(100, 0.05, characteristic_length_lu=128, characteristic_length_pu=2 * np.pi)
+    assert u.relaxation_parameter_lu == pytest.approx(0.610851251684408, rel=1e-14)
+    assert u.convert_time_to_pu(u.convert_time_to_lu(3.0)) == pytest.approx(3.0)
+
+
+def test_reporter_cadence_and_deprecated_step():
+    """sim(3); sim(2) -> reporters see i = 0..5."""
+    flow = lt.TaylorGreenVortex(ctx(), [8, 8], 10, 0.05, lt.D2Q9())
+
+    class Seen(lt.Reporter):
+        def __init__(self):
+            super().__init__(1)
+            self.i = []
+
+        def __call__(self, simulation):
+            self.i.append(simulation.flow.i)
+    rep = Seen()
+    sim = lt.Simulation(flow, lt.BGKCollision(0.8), [rep])
+    sim(3)
+    with pytest.warns(DeprecationWarning):
+        sim.step(2)
+    assert rep.i == [0, 1, 2, 3, 4, 5]
+    assert sim._steps_to_next_report(100) == 1
+    rep.interval = 4
+    assert sim._steps_to_next_report(100) == 3        # i = 5 -> next multiple of 4 is 8
+    sim.reporter.clear()
+    assert sim._steps_to_next_report(100) == 100
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    flow = lt.TaylorGreenVortex(ctx(), [8, 8], 10, 0.05, lt.D2Q9())
+    f0 = copy(flow.f)
+    flow.dump(tmp_path / "f.pkl")
+    lt.Simulation(flow, lt.BGKCollision(0.8), [])(3)
+    assert not torch.equal(flow.f, f0)
+    flow.load(tmp_path / "f.pkl")
+    assert torch.equal(flow.f, f0)
+
+
+def test_torch_gradient_orders():
+    x = torch.linspace(0, 2 * np.pi * (1 - 1 / 64), 64, dtype=torch.float64)
+    g = torch.meshgrid(x, x, indexing="ij")
+    f = torch.sin(g[0]) * torch.cos(2 * g[1])
+    dx = float(x[1] - x[0])
+    for order, tol in ((2, 2e-2), (4, 2e-4), (6, 2e-6)):
+        grad = lt.torch_gradient(f, dx=dx, order=order)
+        assert torch.allclose(grad[0], torch.cos(g[0]) * torch.cos(2 * g[1]), atol=tol)
+        assert torch.allclose(grad[1], -2 * torch.sin(g[0]) * torch.sin(2 * g[1]), atol=4 * tol)
+
+
+# ------------------------------------------------------------------ C ABI (no compute calls)
+def test_library_exports_every_declared_symbol():
+    from lettuce_amd import _native
+    header = open(os.path.join(ROOT, "include", "lettuce_hip.h")).read()
+    declared = set(re.findall(r"\b(lt_[a-z_]+)\s*\(", header))
+    assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
+    lib = _native.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.lt_abi_version() == 1
+    # argument checks that run before any HIP call
+    bad = _native._PlanDesc()
+    bad.abi_version = 99
+    handle = _native.ctypes.c_void_p()
+    assert lib.lt_plan_create(_native.ctypes.byref(bad), _native.ctypes.byref(handle)) == 1
+    assert b"ABI version" in lib.lt_last_error()
+    bad.abi_version, bad.stencil, bad.dims, bad.collision = 1, 1, 3, 2     # KBC on D3Q19
+    bad.shape[0] = bad.shape[1] = bad.shape[2] = 8
+    assert lib.lt_plan_create(_native.ctypes.byref(bad), _native.ctypes.byref(handle)) == 2
+    assert b"KBC" in lib.lt_last_error()
+
+
+def test_native_context_never_falls_back(monkeypatch):
+    """use_native with no engine library must raise, not run torch ops."""
+    from lettuce_amd import _native
+    flow = lt.TaylorGreenVortex(ctx(), [8, 8], 10, 0.05, lt.D2Q9())
+    flow.context.use_native = True                    # as if a GPU context had been requested
+    monkeypatch.setattr(_native, "_LIB", None)
+    monkeypatch.setattr(_native, "library_path", lambda: "/nonexistent/liblettuce_hip.so")
+    with pytest.raises(_native.NativeEngineError, match="not found"):
+        lt.Simulation(flow, lt.BGKCollision(0.8), [])
+    # and a component without kernels is refused loudly
+    monkeypatch.undo()
+    flow3 = UniformFlow(ctx(), [4, 4, 4], 1, 0.01, lt.D3Q15())
+    flow3.context.use_native = True
+    with pytest.raises(lt.LettuceException, match="D3Q15"):
+        lt.Simulation(flow3, lt.BGKCollision(0.8), [])

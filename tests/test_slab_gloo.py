@@ -1,0 +1,82 @@
+"""N > 1 path on CPU: world_size-2 (and 4) gloo processes run the z-slab driver with an
+oracle-backed engine and must reproduce the single-domain oracle exactly; also checks that the
+slab-aware initial condition equals the global one plane for plane."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _worker(rank, world, port, res, lattice, collision, steps, dtype_name, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lettuce_amd as lt
+    from slab_cpu_engine import OracleSlabEngine
+    dtype = getattr(torch, dtype_name)
+    ctx = lt.Context("cpu", dtype, use_native=False)
+    slab = lt.ZSlab(res)
+    stencil = getattr(lt, lattice)()
+    flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 400, 0.1, stencil, slab=slab)
+    coll = lt.BGKCollision(flow.units.relaxation_parameter_lu) if collision == "bgk" else lt.KBCCollision()
+    engine = OracleSlabEngine(lattice, dtype, collision)
+    sim = lt.SlabSimulation(flow, coll, slab, engine=engine)
+    f0 = sim.gather_f()
+    sim(steps)
+    f1 = sim.gather_f()
+    ke = sim.kinetic_energy_pu()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "out.npz"), f0=f0.numpy(), f1=f1.numpy(), ke=ke)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+CASES = [(2, [8, 6, 8], "D3Q19", "bgk", 5, "float64"),
+         (4, [6, 8, 8], "D3Q27", "kbc", 3, "float64"),
+         (2, [8, 8, 4], "D3Q19", "bgk", 4, "float32")]
+
+
+@pytest.mark.parametrize("world,res,lattice,collision,steps,dtype_name", CASES,
+                         ids=[f"{c[0]}ranks-{c[2]}-{c[3]}-{c[5]}" for c in CASES])
+def test_slab_ranks_reproduce_single_domain(tmp_path, world, res, lattice, collision, steps, dtype_name):
+    from oracle import lettuce_oracle as orc
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, res, lattice, collision, steps, dtype_name, str(tmp_path)),
+             nprocs=world, join=True)
+    got = np.load(tmp_path / "out.npz")
+    dtype = getattr(torch, dtype_name)
+    ref = orc.taylor_green(res, 400, 0.1, lattice, dtype, collision)
+    tol = 1e-13 if dtype_name == "float64" else 1e-6
+    # slab init == global init (torch's vectorised sin/cos may differ in the last bit between
+    # tensor shapes, hence not assert_array_equal)
+    np.testing.assert_allclose(got["f0"], ref.f.numpy(), rtol=0, atol=tol / 50)
+    ref.step(steps)
+    np.testing.assert_allclose(got["f1"], ref.f.numpy(), rtol=0, atol=tol)
+    ke_ref = float(orc.kinetic_energy_pu(ref.f, ref.lat, ref.units))
+    assert float(got["ke"]) == pytest.approx(ke_ref, rel=1e-12 if dtype_name == "float64" else 1e-5)
+
+
+def test_single_rank_slab_self_exchange():
+    import lettuce_amd as lt
+    from slab_cpu_engine import OracleSlabEngine
+    from oracle import lettuce_oracle as orc
+    res = [6, 4, 5]
+    ctx = lt.Context("cpu", torch.float64, use_native=False)
+    slab = lt.ZSlab(res, rank=0, world_size=1)
+    flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 100, 0.1, lt.D3Q19(), slab=slab)
+    sim = lt.SlabSimulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
+                            engine=OracleSlabEngine("D3Q19", torch.float64, "bgk"))
+    ref = orc.taylor_green(res, 100, 0.1, "D3Q19", torch.float64)
+    np.testing.assert_allclose(sim.gather_f().numpy(), ref.f.numpy(), rtol=0, atol=2e-15)
+    sim(3); sim(2)
+    ref.step(5)
+    np.testing.assert_allclose(sim.gather_f().numpy(), ref.f.numpy(), rtol=0, atol=1e-13)
