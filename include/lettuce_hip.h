@@ -177,9 +177,19 @@ int lt_plan_kernel_info(lt_plan *plan, int32_t *vec_width, int32_t *threads_per_
                         int64_t *blocks_per_launch);
 /* Name of the fused kernel variant this plan launches (for matching rocprof rows). */
 const char *lt_plan_kernel_name(lt_plan *plan);
-/* Tuning knob for experiments: 0 = aligned vector load + one neighbour element,
- * 1 = unaligned vector load, 2 = aligned vector load + cross-lane shift. */
+/* 16-byte variant only: 0 = aligned vector load + one neighbour element, 1 = unaligned vector
+ * load, 2 = aligned vector load + cross-lane shift. */
 int lt_plan_set_shift_policy(lt_plan *plan, int32_t policy);
+/* Diagnostic: dst[0:n_bytes] = src[0:n_bytes] with 16-byte accesses, the same cache-policy bits
+ * and grid cap as lt_plan_set_tuning.  bench.py uses it to measure this device's copy ceiling. */
+int lt_probe_copy(void *dst_dev, const void *src_dev, int64_t n_bytes, int32_t cache_policy,
+                  int32_t max_blocks, void *stream);
+/* Tuning knobs.  cache_policy: -1 = automatic (nontemporal stores when the populations exceed
+ * the caches), else bit 0 = nontemporal loads, bit 1 = nontemporal stores (the one-node-per-
+ * thread kernels exist for 0 and 2).  max_blocks > 0 caps the grid (grid-stride loop).
+ * wide != 0 switches the hot kernel (fused, BGK, no masks) to its 16-byte-per-lane A/B variant,
+ * whose shift handling lt_plan_set_shift_policy selects. */
+int lt_plan_set_tuning(lt_plan *plan, int32_t cache_policy, int32_t max_blocks, int32_t wide);
 
 #ifdef __cplusplus
 }

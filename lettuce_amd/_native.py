@@ -78,6 +78,8 @@ SYMBOLS = {
                                            ctypes.POINTER(_i64)]),
     "lt_plan_kernel_name": (ctypes.c_char_p, [_vp]),
     "lt_plan_set_shift_policy": (ctypes.c_int, [_vp, _i32]),
+    "lt_plan_set_tuning": (ctypes.c_int, [_vp, _i32, _i32, _i32]),
+    "lt_probe_copy": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
 }
 
 _LIB = None
@@ -122,6 +124,16 @@ def _stream_handle() -> int:
 
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def probe_copy(dst: torch.Tensor, src: torch.Tensor, cache_policy: int = 0, max_blocks: int = 0):
+    """dst <- src with the engine's plain 16-byte streaming copy kernel (copy-ceiling probe)."""
+    lib = load_library()
+    nbytes = src.numel() * src.element_size()
+    code = lib.lt_probe_copy(_ptr(dst), _ptr(src), nbytes, int(cache_policy), int(max_blocks),
+                             _stream_handle())
+    if code != 0:
+        raise NativeEngineError(lib.lt_last_error().decode())
 
 
 class Plan:
@@ -331,3 +343,7 @@ class Plan:
 
     def set_shift_policy(self, policy: int):
         self._check(self.lib.lt_plan_set_shift_policy(self._handle, int(policy)))
+
+    def set_tuning(self, cache_policy: int = -1, max_blocks: int = 0, wide: bool = False):
+        self._check(self.lib.lt_plan_set_tuning(self._handle, int(cache_policy), int(max_blocks),
+                                                int(bool(wide))))

@@ -48,6 +48,18 @@ const Unit kUnits[3][2] = {
 
 constexpr int kReduceBlocks = 1024;
 
+// plain streaming copy, 16 B per lane: the device-copy ceiling the roofline fraction is quoted
+// against next to the 8 TB/s spec number
+typedef float probe_f4 __attribute__((ext_vector_type(4)));
+template <int TUNE>
+__global__ void __launch_bounds__(256) probe_copy_kernel(const probe_f4 *__restrict__ src,
+                                                         probe_f4 *__restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const probe_f4 v = (TUNE & 1) ? __builtin_nontemporal_load(src + i) : src[i];
+    if (TUNE & 2) __builtin_nontemporal_store(v, dst + i); else dst[i] = v;
+  }
+}
+
 }  // namespace
 
 struct lt_plan {
@@ -59,6 +71,9 @@ struct lt_plan {
   long long N;               // n0*n1*n2
   int wide_ok;               // n0 divisible by the 16-byte vector width
   int shift;
+  int tune = -1;             // cache policy: -1 = automatic
+  int grid_cap = 0;
+  int want_wide = 0;         // 16-byte accesses for the hot kernel (A/B experiments)
   // engine-owned device scratch
   unsigned char *node = nullptr;
   unsigned *nsm_bits = nullptr;
@@ -121,6 +136,15 @@ int check_boundary(const lt_plan *p, const lt_boundary_desc &b, int n_abb_before
   }
 }
 
+// Nontemporal stores pay off when the two population buffers cannot stay in the caches
+// (32 MiB L2 + 256 MiB Infinity Cache); small grids keep cached stores.
+int resolve_tune(const lt_plan *p, int wide) {
+  if (wide) return p->tune < 0 ? 0 : p->tune;
+  if (p->tune == 0 || p->tune == 2) return p->tune;
+  const long long bytes = 2ll * p->unit.q * p->N * p->esize;
+  return bytes > (128ll << 20) ? 2 : 0;
+}
+
 int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long pb, long long pe,
          void *stream) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
@@ -146,8 +170,11 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = mode;
   a.masked = p->masked;
   const bool aligned = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
-  a.wide = (p->wide_ok && aligned) ? 1 : 0;
-  a.shift = (a.wide && mode == lt::kFused && !a.masked && a.coll == LT_COLLISION_BGK) ? p->shift : 0;
+  const bool hot = mode == lt::kFused && !a.masked && a.coll == LT_COLLISION_BGK;
+  a.wide = (p->want_wide && hot && p->wide_ok && aligned) ? 1 : 0;
+  a.shift = a.wide ? p->shift : 0;
+  a.tune = resolve_tune(p, a.wide);
+  a.grid_cap = p->grid_cap;
   a.stream = static_cast<hipStream_t>(stream);
   const int r = p->unit.step(a);
   if (r == lt::kNoKernel)
@@ -362,7 +389,7 @@ int lt_mass(lt_plan *p, const void *f, double *out, void *s) {
 
 int lt_plan_kernel_info(lt_plan *p, int32_t *vec, int32_t *tpb, int64_t *blocks) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
-  const int v = p->wide_ok ? 16 / p->esize : 1;
+  const int v = (p->want_wide && p->wide_ok) ? 16 / p->esize : 1;
   if (vec) *vec = v;
   if (tpb) *tpb = lt::kThreads;
   if (blocks) {
@@ -377,17 +404,50 @@ const char *lt_plan_kernel_name(lt_plan *p) {
   lt::StepArgs a;
   memset(&a, 0, sizeof a);
   a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = lt::kFused;
-  a.masked = p->masked; a.wide = p->wide_ok;
-  a.shift = (a.wide && !a.masked && a.coll == LT_COLLISION_BGK) ? p->shift : 0;
+  a.masked = p->masked;
+  a.wide = (p->want_wide && p->wide_ok && !a.masked && a.coll == LT_COLLISION_BGK) ? 1 : 0;
+  a.shift = a.wide ? p->shift : 0;
+  a.tune = resolve_tune(p, a.wide);
   const char *n = p->unit.name(a);
   snprintf(p->kernel_name, sizeof p->kernel_name, "%s", n ? n : "");
   return p->kernel_name;
+}
+
+int lt_probe_copy(void *dst, const void *src, int64_t n_bytes, int32_t cache_policy,
+                  int32_t max_blocks, void *stream) {
+  if (!dst || !src || n_bytes < 16 || n_bytes % 16 != 0 || (uintptr_t)dst % 16 || (uintptr_t)src % 16)
+    return fail(LT_ERR_INVALID, "probe copy needs 16-byte aligned buffers and size");
+  const size_t n = (size_t)n_bytes / 16;
+  size_t grid = (n + 255) / 256;
+  if (max_blocks > 0 && grid > (size_t)max_blocks) grid = (size_t)max_blocks;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const probe_f4 *sp = static_cast<const probe_f4 *>(src);
+  probe_f4 *dp = static_cast<probe_f4 *>(dst);
+  switch (cache_policy) {
+    case 0: hipLaunchKernelGGL(probe_copy_kernel<0>, dim3((unsigned)grid), dim3(256), 0, s, sp, dp, n); break;
+    case 1: hipLaunchKernelGGL(probe_copy_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, sp, dp, n); break;
+    case 2: hipLaunchKernelGGL(probe_copy_kernel<2>, dim3((unsigned)grid), dim3(256), 0, s, sp, dp, n); break;
+    case 3: hipLaunchKernelGGL(probe_copy_kernel<3>, dim3((unsigned)grid), dim3(256), 0, s, sp, dp, n); break;
+    default: return fail(LT_ERR_INVALID, "cache policy %d", cache_policy);
+  }
+  LT_HIP(hipGetLastError());
+  return LT_OK;
 }
 
 int lt_plan_set_shift_policy(lt_plan *p, int32_t policy) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (policy < 0 || policy > 2) return fail(LT_ERR_INVALID, "shift policy %d", policy);
   p->shift = policy;
+  return LT_OK;
+}
+
+int lt_plan_set_tuning(lt_plan *p, int32_t cache_policy, int32_t max_blocks, int32_t wide) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (cache_policy < -1 || cache_policy > 3) return fail(LT_ERR_INVALID, "cache policy %d", cache_policy);
+  if (max_blocks < 0) return fail(LT_ERR_INVALID, "max_blocks %d", max_blocks);
+  p->tune = cache_policy;
+  p->grid_cap = max_blocks;
+  p->want_wide = wide ? 1 : 0;
   return LT_OK;
 }
 

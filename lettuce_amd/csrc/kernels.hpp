@@ -77,18 +77,27 @@ template <> struct Vec<float, 4> {
   typedef float utype __attribute__((ext_vector_type(4), aligned(4)));
   typedef unsigned char mtype __attribute__((ext_vector_type(4)));
 };
+template <> struct Vec<float, 2> {
+  typedef float type __attribute__((ext_vector_type(2)));
+  typedef float utype __attribute__((ext_vector_type(2), aligned(4)));
+  typedef unsigned char mtype __attribute__((ext_vector_type(2)));
+};
 template <> struct Vec<double, 2> {
   typedef double type __attribute__((ext_vector_type(2)));
   typedef double utype __attribute__((ext_vector_type(2), aligned(8)));
   typedef unsigned char mtype __attribute__((ext_vector_type(2)));
 };
 
-template <typename T, int VEC>
+// NT = nontemporal hint: the populations are streamed once per step and the working set
+// (2.5 GB at 256^3) is far beyond L2 + Infinity Cache, so nothing is gained by keeping lines.
+template <typename T, int VEC, bool NT = false>
 __device__ __forceinline__ void vload(const T *__restrict__ p, T (&r)[VEC]) {
   if constexpr (VEC == 1) {
-    r[0] = *p;
+    r[0] = NT ? __builtin_nontemporal_load(p) : *p;
   } else {
-    const typename Vec<T, VEC>::type v = *reinterpret_cast<const typename Vec<T, VEC>::type *>(p);
+    using V = typename Vec<T, VEC>::type;
+    const V *vp = reinterpret_cast<const V *>(p);
+    const V v = NT ? __builtin_nontemporal_load(vp) : *vp;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) r[k] = v[k];
   }
@@ -99,15 +108,17 @@ __device__ __forceinline__ void vload_unaligned(const T *__restrict__ p, T (&r)[
 #pragma unroll
   for (int k = 0; k < VEC; ++k) r[k] = v[k];
 }
-template <typename T, int VEC>
+template <typename T, int VEC, bool NT = false>
 __device__ __forceinline__ void vstore(T *__restrict__ p, const T (&r)[VEC]) {
   if constexpr (VEC == 1) {
-    *p = r[0];
+    if constexpr (NT) __builtin_nontemporal_store(r[0], p); else *p = r[0];
   } else {
-    typename Vec<T, VEC>::type v;
+    using V = typename Vec<T, VEC>::type;
+    V v;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) v[k] = r[k];
-    *reinterpret_cast<typename Vec<T, VEC>::type *>(p) = v;
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<V *>(p));
+    else *reinterpret_cast<V *>(p) = v;
   }
 }
 
@@ -139,7 +150,9 @@ __device__ __forceinline__ Coord make_coord(const KParams<T> &p, int c0, int c1,
 //   0: aligned 16-B load + one neighbour element load
 //   1: unaligned 16-B load (row ends handled separately)
 //   2: aligned 16-B load + cross-lane shift (ds_bpermute), neighbour element only at wave/row edges
-template <typename T, class S, int LAYOUT, bool STREAM, int VEC, int SHIFT>
+//   3: aligned 16-B load + wave ROTATE: legal when a row is exactly one wave (n0 == 64 * VEC);
+//      the periodic wrap is then the rotation itself and no neighbour element is ever loaded
+template <typename T, class S, int LAYOUT, bool STREAM, int VEC, int SHIFT, bool NTL = false>
 __device__ __forceinline__ void gather(const KParams<T> &p, const Coord &c, T (&f)[S::Q][VEC]) {
   using M = MemMap<S, LAYOUT>;
   const int n0 = p.n0, n1 = p.n1;
@@ -148,14 +161,14 @@ __device__ __forceinline__ void gather(const KParams<T> &p, const Coord &c, T (&
     constexpr int q = decltype(qc)::value;
     const T *__restrict__ src = p.in + (long long)q * p.N;
     if constexpr (!STREAM) {
-      vload<T, VEC>(src + own, f[q]);
+      vload<T, VEC, NTL>(src + own, f[q]);
     } else {
       constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1), e2 = M::e(q, 2);
       const int s1 = e1 == 0 ? c.c1 : (e1 > 0 ? c.c1m : c.c1p);
       const int s2 = e2 == 0 ? c.c2 : (e2 > 0 ? c.c2m : c.c2p);
       const unsigned row = (unsigned)(s2 * n1 + s1) * (unsigned)n0;
       if constexpr (e0 == 0) {
-        vload<T, VEC>(src + row + c.c0, f[q]);
+        vload<T, VEC, NTL>(src + row + c.c0, f[q]);
       } else if constexpr (VEC == 1) {
         const int s0 = e0 > 0 ? (c.c0 == 0 ? n0 - 1 : c.c0 - 1) : (c.c0 == n0 - 1 ? 0 : c.c0 + 1);
         f[q][0] = src[row + s0];
@@ -166,16 +179,18 @@ __device__ __forceinline__ void gather(const KParams<T> &p, const Coord &c, T (&
             vload_unaligned<T, VEC>(src + row + c.c0 - 1, f[q]);
           } else {
             T a[VEC];
-            vload<T, VEC>(src + row, a);
+            vload<T, VEC, NTL>(src + row, a);
             f[q][0] = src[row + n0 - 1];
 #pragma unroll
             for (int k = 1; k < VEC; ++k) f[q][k] = a[k - 1];
           }
         } else {
           T a[VEC];
-          vload<T, VEC>(src + row + c.c0, a);
+          vload<T, VEC, NTL>(src + row + c.c0, a);
           T nb;
-          if constexpr (SHIFT == 2) {
+          if constexpr (SHIFT == 3) {
+            nb = __shfl(a[VEC - 1], (threadIdx.x + 63) & 63);
+          } else if constexpr (SHIFT == 2) {
             nb = __shfl_up(a[VEC - 1], 1);
             if ((threadIdx.x & 63) == 0 || c.c0 == 0) nb = src[row + (c.c0 == 0 ? n0 - 1 : c.c0 - 1)];
           } else {
@@ -193,16 +208,18 @@ __device__ __forceinline__ void gather(const KParams<T> &p, const Coord &c, T (&
             vload_unaligned<T, VEC>(src + row + c.c0 + 1, f[q]);
           } else {
             T a[VEC];
-            vload<T, VEC>(src + row + c.c0, a);
+            vload<T, VEC, NTL>(src + row + c.c0, a);
 #pragma unroll
             for (int k = 0; k < VEC - 1; ++k) f[q][k] = a[k + 1];
             f[q][VEC - 1] = src[row];
           }
         } else {
           T a[VEC];
-          vload<T, VEC>(src + row + c.c0, a);
+          vload<T, VEC, NTL>(src + row + c.c0, a);
           T nb;
-          if constexpr (SHIFT == 2) {
+          if constexpr (SHIFT == 3) {
+            nb = __shfl(a[0], (threadIdx.x + 1) & 63);
+          } else if constexpr (SHIFT == 2) {
             nb = __shfl_down(a[0], 1);
             if ((threadIdx.x & 63) == 63 || last) nb = src[row + (last ? 0 : c.c0 + VEC)];
           } else {
@@ -479,11 +496,13 @@ __device__ __forceinline__ void abb_outlet(const KParams<T> &p, int slot, int c0
 }
 
 // ---- the kernel ---------------------------------------------------------------------------
+// TUNE bit 0: nontemporal loads, bit 1: nontemporal stores.  The grid may be smaller than the
+// work (grid-stride loop); by default it covers it exactly and the loop runs once.
 template <typename T, class S, int LAYOUT, int COLL, bool STREAM, bool COLLIDE, bool MASKED,
-          int VEC, int SHIFT>
-__global__ void __launch_bounds__(kThreads) lbm_kernel(const KParams<T> p) {
-  const unsigned v = blockIdx.x * (unsigned)kThreads + threadIdx.x;
-  if (v >= p.nvec_total) return;
+          int VEC, int SHIFT, int TUNE = 0>
+__device__ __forceinline__ void lbm_body(const KParams<T> &p) {
+  for (unsigned v = blockIdx.x * blockDim.x + threadIdx.x; v < p.nvec_total;
+       v += gridDim.x * blockDim.x) {
   const unsigned rowid = v / (unsigned)p.nv0;
   const int c0 = (int)(v - rowid * (unsigned)p.nv0) * VEC;
   const int r2 = (int)(rowid / (unsigned)p.n1);
@@ -493,7 +512,7 @@ __global__ void __launch_bounds__(kThreads) lbm_kernel(const KParams<T> p) {
   const unsigned own = (unsigned)(c2 * p.n1 + c1) * (unsigned)p.n0 + (unsigned)c0;
 
   T f[S::Q][VEC];
-  gather<T, S, LAYOUT, STREAM, VEC, SHIFT>(p, c, f);
+  gather<T, S, LAYOUT, STREAM, VEC, SHIFT, (TUNE & 1) != 0>(p, c, f);
 
   unsigned char nd[VEC];
   if constexpr (MASKED) {
@@ -551,8 +570,15 @@ __global__ void __launch_bounds__(kThreads) lbm_kernel(const KParams<T> p) {
 
   static_for<S::Q>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
-    vstore<T, VEC>(p.out + (long long)q * p.N + own, f[q]);
+    vstore<T, VEC, (TUNE & 2) != 0>(p.out + (long long)q * p.N + own, f[q]);
   });
+  }
+}
+
+template <typename T, class S, int LAYOUT, int COLL, bool STREAM, bool COLLIDE, bool MASKED,
+          int VEC, int SHIFT, int TUNE = 0>
+__global__ void __launch_bounds__(kThreads) lbm_kernel(const KParams<T> p) {
+  lbm_body<T, S, LAYOUT, COLL, STREAM, COLLIDE, MASKED, VEC, SHIFT, TUNE>(p);
 }
 
 // ---- auxiliary kernels --------------------------------------------------------------------

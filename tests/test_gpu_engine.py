@@ -215,24 +215,40 @@ def test_whole_field_operators(lat, dt):
     np.testing.assert_array_equal(out.cpu().numpy(), g["bounce_back"])
 
 
-def test_fused_equals_collide_then_stream_and_shift_policies_agree():
-    g = golden("tgv3d_d3q19_bgk_32_f32")
-    f = dev(g["f0"])
-    tau = float(g["tau"])
-    plan = plan_for("D3Q19", torch.float32, "bgk", g["f0"].shape[1:])
-    tmp, a, b = torch.empty_like(f), torch.empty_like(f), torch.empty_like(f)
-    plan.stream(f, tmp)
-    plan.collide(tmp, a, tau)
-    results = []
-    for policy in (0, 1, 2):
-        plan.set_shift_policy(policy)
+def test_fused_equals_collide_then_stream_and_ab_variants_agree():
+    """fused == stream then collide; the 16-byte A/B variants of the hot kernel (three ways of
+    resolving the shift along the contiguous axis, cached / nontemporal) give the same
+    populations as the default one-node-per-thread kernel."""
+    for name, lat in (("tgv3d_d3q19_bgk_32_f32", "D3Q19"), ("tgv3d_d3q27_bgk_16_f64", "D3Q27")):
+        g = golden(name)
+        f = dev(g["f0"])
+        tau = float(g["tau"])
+        plan = plan_for(lat, f.dtype, "bgk", g["f0"].shape[1:])
+        assert plan.kernel_info()["vec"] == 1
+        tmp, a, b = torch.empty_like(f), torch.empty_like(f), torch.empty_like(f)
+        plan.stream(f, tmp)
+        plan.collide(tmp, a, tau)
         plan.stream_collide(f, b, tau)
-        results.append(b.clone())
-    # same arithmetic on the same values; only fp-contraction choices may differ between
-    # kernel instantiations, so compare to 1 ulp-level instead of bit for bit
-    for r in results:
-        torch.testing.assert_close(r, a, rtol=0, atol=2e-7)
-    assert torch.equal(results[1], results[0]) and torch.equal(results[2], results[0])
+        # same arithmetic on the same values; only fp-contraction choices may differ between
+        # kernel instantiations, so compare at the 1-ulp level instead of bit for bit
+        tol = 2e-7 if f.dtype == torch.float32 else 4e-16
+        torch.testing.assert_close(b, a, rtol=0, atol=tol)
+        for cache in (0, 2):
+            plan.set_tuning(cache, 0, False)
+            c = torch.empty_like(f)
+            plan.stream_collide(f, c, tau)
+            assert torch.equal(c, b)
+        for shift, cache in ((0, 0), (1, 0), (2, 0), (0, 2), (2, 3)):
+            plan.set_tuning(cache, 0, True)
+            plan.set_shift_policy(shift)
+            assert plan.kernel_info()["vec"] == 16 // f.element_size()
+            c = torch.empty_like(f)
+            plan.stream_collide(f, c, tau)
+            torch.testing.assert_close(c, b, rtol=0, atol=tol)
+        plan.set_tuning(-1, 512, False)           # capped grid -> grid-stride loop
+        c = torch.empty_like(f)
+        plan.stream_collide(f, c, tau)
+        assert torch.equal(c, b)
 
 
 def test_energy_decay_series_fp64():
@@ -256,7 +272,7 @@ def test_full_size_properties_256cubed_fp32():
     by collide-stream, streaming 256 times is the identity, lt_continue == lt_run."""
     n = 256
     plan = plan_for("D3Q19", torch.float32, "bgk", [n] * 3)
-    assert plan.kernel_info()["vec"] == 4
+    assert plan.kernel_info()["vec"] == 1
     torch.manual_seed(0)
     w = torch.tensor(orc.LATTICES["D3Q19"].w, dtype=torch.float32, device="cuda").reshape(19, 1, 1, 1)
     f0 = w * (1 + 0.05 * torch.rand(19, n, n, n, device="cuda"))

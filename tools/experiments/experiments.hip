@@ -1,0 +1,90 @@
+// Development-only variants of the hot kernel (D3Q19 / D3Q27, BGK, fused, periodic), built into
+// tools/experiments/libexperiments.so and timed by tools/experiments/sweep.py.  Not part of
+// the product library.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include "kernels.hpp"
+
+using namespace lt;
+
+template <typename T, class S, int VEC, int SHIFT, int TUNE, int MINW>
+__global__ void __launch_bounds__(512, MINW) exp_kernel(const KParams<T> p) {
+  lbm_body<T, S, 0, 1, true, true, false, VEC, SHIFT, TUNE>(p);
+}
+
+template <typename T, class S, int VEC, int SHIFT, int TUNE, int MINW>
+static int go(const void *in, void *out, int n0, int n1, int n2, double tau, int cap, int tpb, hipStream_t st) {
+  KParams<T> p;
+  p.in = (const T *)in; p.out = (T *)out;
+  p.n0 = n0; p.n1 = n1; p.n2 = n2; p.nv0 = n0 / VEC; p.p_begin = 0; p.wrap2 = 1;
+  p.N = (long long)n0 * n1 * n2;
+  p.nvec_total = (unsigned)((long long)p.nv0 * n1 * n2);
+  p.tau_inv = (T)(1.0 / tau); p.beta = p.inv_beta = 0;
+  p.node = nullptr; p.nsm_bits = nullptr; p.bt = nullptr; p.nb = 0;
+  if (tpb <= 0) tpb = 256;
+  unsigned grid = (p.nvec_total + tpb - 1) / tpb;
+  if (cap > 0 && grid > (unsigned)cap) grid = cap;
+  if (SHIFT == 3 && n0 != 64 * VEC) return -2;
+  hipLaunchKernelGGL((exp_kernel<T, S, VEC, SHIFT, TUNE, MINW>), dim3(grid), dim3(tpb), 0, st, p);
+  return (int)hipGetLastError();
+}
+
+#define V(ID, TT, SS, VEC, SHIFT, TUNE, MINW) \
+  case ID: return go<TT, SS, VEC, SHIFT, TUNE, MINW>(in, out, n0, n1, n2, tau, cap, tpb, (hipStream_t)stream);
+
+extern "C" int lt_experiment(int id, const void *in, void *out, int n0, int n1, int n2, double tau,
+                             int cap, int tpb, void *stream) {
+  switch (id) {
+    // D3Q19 fp32
+    V(0, float, D3Q19, 4, 0, 0, 1)
+    V(1, float, D3Q19, 4, 2, 3, 1)
+    V(2, float, D3Q19, 4, 3, 3, 1)
+    V(3, float, D3Q19, 4, 3, 2, 1)
+    V(4, float, D3Q19, 4, 3, 0, 1)
+    V(5, float, D3Q19, 4, 3, 1, 1)
+    V(6, float, D3Q19, 4, 0, 0, 2)
+    V(7, float, D3Q19, 4, 3, 3, 2)
+    V(8, float, D3Q19, 4, 3, 3, 5)
+    V(9, float, D3Q19, 4, 3, 3, 6)
+    V(10, float, D3Q19, 2, 0, 0, 1)
+    V(11, float, D3Q19, 2, 2, 3, 1)
+    V(12, float, D3Q19, 2, 0, 2, 1)
+    V(13, float, D3Q19, 4, 0, 2, 3)
+    V(14, float, D3Q19, 4, 2, 2, 1)
+    V(15, float, D3Q19, 4, 2, 1, 1)
+    V(16, float, D3Q19, 4, 3, 3, 4)
+    V(17, float, D3Q19, 4, 0, 0, 4)
+    V(18, float, D3Q19, 4, 2, 3, 4)
+    V(19, float, D3Q19, 4, 3, 2, 4)
+    // D3Q19 fp64
+    V(20, double, D3Q19, 2, 0, 0, 1)
+    V(21, double, D3Q19, 2, 2, 3, 1)
+    V(22, double, D3Q19, 2, 2, 2, 1)
+    V(23, double, D3Q19, 2, 0, 2, 1)
+    V(24, double, D3Q19, 2, 2, 3, 2)
+    V(25, double, D3Q19, 1, 0, 0, 1)
+    V(26, double, D3Q19, 1, 0, 2, 1)
+    // D3Q27 fp32
+    V(30, float, D3Q27, 4, 0, 0, 1)
+    V(31, float, D3Q27, 4, 2, 3, 1)
+    V(32, float, D3Q27, 4, 3, 3, 1)
+    V(33, float, D3Q27, 4, 3, 2, 1)
+    V(34, float, D3Q27, 4, 3, 3, 2)
+    V(35, float, D3Q27, 2, 0, 2, 1)
+    V(36, float, D3Q27, 4, 3, 3, 3)
+    V(37, float, D3Q27, 4, 0, 2, 3)
+    V(38, float, D3Q27, 2, 2, 3, 1)
+    V(40, float, D3Q19, 1, 0, 0, 1)
+    V(41, float, D3Q19, 1, 0, 2, 1)
+    V(42, float, D3Q19, 2, 0, 2, 4)
+    V(43, float, D3Q19, 2, 0, 3, 1)
+    V(44, float, D3Q19, 2, 2, 2, 1)
+    V(45, float, D3Q19, 2, 1, 2, 1)
+    V(50, double, D3Q19, 1, 0, 2, 4)
+    V(51, double, D3Q19, 1, 0, 3, 1)
+    V(61, float, D3Q27, 1, 0, 2, 1)
+    V(62, float, D3Q27, 2, 0, 2, 2)
+    V(63, float, D3Q27, 2, 0, 0, 1)
+    default: return -1;
+  }
+}

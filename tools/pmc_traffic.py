@@ -1,0 +1,57 @@
+"""Summarise the rocprofv3 runs of tools/gpu_round.sh into profiles/:
+  <tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats summary (LBM kernels + top rows)
+  traffic.json                HBM bytes per launch of the LBM kernels from the two --pmc passes
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE
+reports exactly half of the bytes of a wide coalesced streaming read, WRITE_SIZE is exact for
+streaming stores.  The factor is calibrated in-run on the collide-only kernel
+(lbm_kernel<..., false, true, ...>), which reads every population exactly once with the same
+access width as the fused kernel: factor = algorithmic read bytes / (FETCH_SIZE * 1024).
+"""
+import csv, glob, json, os, statistics, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def pmc(path):
+    out = {}
+    for row in csv.DictReader(open(path)):
+        if "lbm_kernel" in row["Kernel_Name"]:
+            out.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+    return {k: statistics.median(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
+
+
+def main(tag, nodes=256 ** 3, q=19, esize=4, workload="tgv3d_d3q19_bgk_f32_256"):
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    rows = list(csv.reader(open(stats)))
+    keep = [rows[0]] + [r for r in rows[1:] if "lbm_kernel" in r[0]] + \
+           [r for r in rows[1:8] if "lbm_kernel" not in r[0]]
+    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
+        csv.writer(fh, quoting=csv.QUOTE_ALL).writerows(keep)
+    fetch, n_f = pmc(glob.glob(os.path.join(src, "pmc_FETCH_SIZE", "*", "*_counter_collection.csv"))[0])
+    write, n_w = pmc(glob.glob(os.path.join(src, "pmc_WRITE_SIZE", "*", "*_counter_collection.csv"))[0])
+    alg = q * esize * nodes
+    calib = [k for k in fetch if ", false, true, " in k]
+    factor = alg / (fetch[calib[0]] * 1024) if calib else 2.0
+    kernels = []
+    for k in sorted(fetch):
+        rd = fetch[k] * 1024 * factor
+        wr = write.get(k, float("nan")) * 1024
+        kernels.append({"kernel": k, "workload": workload, "launches_sampled": n_f[k],
+                        "FETCH_SIZE_KiB_median": fetch[k], "WRITE_SIZE_KiB_median": write.get(k),
+                        "fetch_correction_factor": round(factor, 4),
+                        "hbm_read_bytes_per_launch": round(rd), "hbm_write_bytes_per_launch": round(wr),
+                        "hbm_bytes_per_launch": round(rd + wr),
+                        "algorithmic_bytes_per_launch": 2 * alg,
+                        "traffic_over_algorithmic": round((rd + wr) / (2 * alg), 4)})
+    json.dump({"tag": tag, "note": __doc__.split("gfx950 corrections")[1].strip(), "kernels": kernels},
+              open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    for k in kernels:
+        print(k["kernel"][:70], k["hbm_bytes_per_launch"], k["traffic_over_algorithmic"])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
