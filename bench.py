@@ -7,9 +7,9 @@
 Workload (BASELINE.json): TaylorGreenVortex3D, D3Q19, BGK, fp32, Re 1600, Ma 0.1, synthetic
 (analytic) initial condition incl. the f_neq initialisation.
   N = 1   256^3 on one GPU (configs[1]) through lt.Simulation and the fused HIP kernel.
-  N > 1   weak scaling, 256^3 nodes per GPU, z-slab decomposition with RCCL ghost-plane
-          exchange: global 256 x 256 x 256N for N = 2, 4 and BASELINE's 512^3 for N = 8
-          (configs[2]: 512 x 512 x 64 per GPU).
+  N > 1   weak scaling at 256^3 = 16.8 M nodes per GPU, z-slab decomposition with RCCL
+          ghost-plane exchange: global 512 x 512 x 64N, i.e. every rank holds the 512 x 512 x 64
+          slab of BASELINE's configs[2] (N = 8 is exactly its 512^3).
 A "step" is one full lattice update (collide, stream) of every node.  The timed region is
 exactly K steps between barrier + device synchronise, max over ranks; value = all nodes of all
 ranks * K / time.  One JSON line is printed by rank 0.
@@ -117,8 +117,8 @@ def main():
         step = sim
         parallelism = "single GPU"
     else:
-        if world == 8 and n == 256:
-            global_res = [512, 512, 512]           # BASELINE configs[2]
+        if n == 256:
+            global_res = [512, 512, 64 * world]    # N = 8: BASELINE configs[2] (512^3)
         else:
             global_res = [n, n, n * world]
         slab = lt.ZSlab(global_res)

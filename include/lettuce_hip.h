@@ -140,6 +140,23 @@ int lt_stream_planes(lt_plan *plan, const void *f_dev, void *f_out_dev,
 int lt_stream_collide_planes(lt_plan *plan, const void *fstar_dev, void *fstar_out_dev,
                              double tau, int64_t plane_begin, int64_t plane_end, void *stream);
 
+/* Fused stream-collide of exactly the two planes `first` < `second` in one launch (the slab's
+ * two boundary planes). */
+int lt_stream_collide_plane_pair(lt_plan *plan, const void *fstar_dev, void *fstar_out_dev,
+                                 double tau, int64_t first, int64_t second, void *stream);
+
+/* Halo packing for the slab driver (no reference counterpart: the reference is single-GPU).
+ * direction = +1 / -1 selects the populations whose velocity component along the slowest memory
+ * axis is +1 / -1 (5 of 19 for D3Q19, 9 of 27 for D3Q27), in ascending q.
+ * lt_slab_crossing reports them; lt_slab_pack copies them from memory plane `plane` of f into the
+ * contiguous buffer buf[n][n1*n0] (one message per direction instead of n); lt_slab_unpack is the
+ * inverse. */
+int lt_slab_crossing(lt_plan *plan, int32_t direction, int32_t *q_out, int32_t *n_out);
+int lt_slab_pack(lt_plan *plan, const void *f_dev, int64_t plane, int32_t direction, void *buf_dev,
+                 void *stream);
+int lt_slab_unpack(lt_plan *plan, void *f_dev, int64_t plane, int32_t direction, const void *buf_dev,
+                   void *stream);
+
 /* n whole lettuce steps (collide, boundaries, stream) starting from post-streaming
  * populations in buf_a (lettuce/_simulation.py:201-203): one collide launch, n-1 fused
  * launches, one stream launch, ping-ponging between the two buffers.  On return

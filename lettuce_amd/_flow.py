@@ -153,7 +153,10 @@ class Flow(ABC):
 
     def j(self, f: Optional[torch.Tensor] = None) -> torch.Tensor:
         """momentum, shape [d, *resolution]"""
-        return self.einsum("qd,q->d", [self.torch_stencil.e, self.f if f is None else f])
+        f = self.f if f is None else f
+        if f.is_cuda:
+            return local_contract(self.torch_stencil.e.t(), f)      # no BLAS on device, see there
+        return self.einsum("qd,q->d", [self.torch_stencil.e, f])
 
     def u(self, f: Optional[torch.Tensor] = None, rho=None, acceleration=None) -> torch.Tensor:
         """velocity; ``acceleration`` adds the half-force correction of a forcing scheme"""
@@ -177,6 +180,8 @@ class Flow(ABC):
     def incompressible_energy(self, f: Optional[torch.Tensor] = None) -> torch.Tensor:
         """0.5 u.u per node"""
         u = self.u(f)
+        if u.is_cuda:
+            return 0.5 * (u * u).sum(dim=0)
         return 0.5 * self.einsum("d,d->", [u, u])
 
     def entropy(self) -> torch.Tensor:
@@ -223,6 +228,22 @@ class Flow(ABC):
             self._f_next = self.context.empty_tensor(self.f.shape)
 
 
+def local_contract(matrix: torch.Tensor, field: torch.Tensor) -> torch.Tensor:
+    """out[i, x] = sum_k matrix[i, k] * field[k, x] as plain elementwise multiply-adds.
+
+    The reference writes these per-node contractions as einsum/tensordot, which torch lowers to
+    a GEMM with one dimension of a few entries and the other of 10^7..10^8 nodes.  On ROCm such
+    a call faulted inside the BLAS kernel for a 512 x 512 x 70 slab (observed on MI355X,
+    torch 2.10 / ROCm 7.2), so device tensors never go through BLAS here; the K <= 27 sum is
+    evaluated term by term (differs from the GEMM result by rounding only)."""
+    out = None
+    for k in range(matrix.shape[1]):
+        col = matrix[:, k].reshape([-1] + [1] * (field.dim() - 1))
+        term = col * field[k][None, ...]
+        out = term if out is None else out.add_(term)
+    return out
+
+
 def initialize_f_neq(flow: "Flow"):
     """f = feq - f(1), the non-equilibrium part estimated from 6th-order finite differences
     of u (lettuce/_flow.py:309-336; Krueger et al. 2017)."""
@@ -235,6 +256,10 @@ def initialize_f_neq(flow: "Flow"):
     # the identity is built in torch's default dtype, as in the reference (fp32-rounded cs^2)
     q_tensor = (torch.einsum("ia,ib->iab", [e, e])
                 - torch.eye(d, device=e.device) * flow.stencil.cs ** 2)
-    pi_1_q = flow.einsum("ab,iab->i", [pi_1, q_tensor])
+    if pi_1.is_cuda:
+        pi_1_q = local_contract(q_tensor.reshape(q_tensor.shape[0], d * d).to(pi_1.dtype),
+                                pi_1.reshape([d * d] + list(pi_1.shape[2:])))
+    else:
+        pi_1_q = flow.einsum("ab,iab->i", [pi_1, q_tensor])
     f_neq = flow.einsum("i,i->i", [flow.torch_stencil.w, pi_1_q])
     return flow.equilibrium(flow, rho, u) - f_neq

@@ -68,6 +68,10 @@ SYMBOLS = {
     "lt_collide_planes": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _i64, _i64, _vp]),
     "lt_stream_planes": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "lt_stream_collide_planes": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _i64, _i64, _vp]),
+    "lt_stream_collide_plane_pair": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _i64, _i64, _vp]),
+    "lt_slab_crossing": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
+    "lt_slab_pack": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "lt_slab_unpack": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "lt_run": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _i64, _vp, ctypes.POINTER(_i32)]),
     "lt_continue": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _i64, _vp, ctypes.POINTER(_i32)]),
     "lt_macroscopic": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -291,6 +295,24 @@ class Plan:
     def stream_collide_planes(self, f, out, tau, begin, end):
         self._check(self.lib.lt_stream_collide_planes(self._handle, _ptr(f), _ptr(out), float(tau),
                                                       int(begin), int(end), _stream_handle()))
+
+    def crossing(self, direction: int):
+        """population indices whose velocity along the slowest memory axis is ``direction``"""
+        qs, n = (ctypes.c_int32 * 9)(), ctypes.c_int32()
+        self._check(self.lib.lt_slab_crossing(self._handle, int(direction), qs, ctypes.byref(n)))
+        return [int(qs[k]) for k in range(n.value)]
+
+    def pack(self, f, plane, direction, buf):
+        self._check(self.lib.lt_slab_pack(self._handle, _ptr(f), int(plane), int(direction), _ptr(buf),
+                                          _stream_handle()))
+
+    def unpack(self, f, plane, direction, buf):
+        self._check(self.lib.lt_slab_unpack(self._handle, _ptr(f), int(plane), int(direction), _ptr(buf),
+                                            _stream_handle()))
+
+    def stream_collide_plane_pair(self, f, out, tau, first, second):
+        self._check(self.lib.lt_stream_collide_plane_pair(self._handle, _ptr(f), _ptr(out), float(tau),
+                                                          int(first), int(second), _stream_handle()))
 
     def run(self, a, b, tau, n_steps, from_fstar=False):
         """n whole steps; returns (result, other): ``result`` holds the new post-streaming

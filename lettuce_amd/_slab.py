@@ -11,13 +11,15 @@ exchange sends straight out of and receives straight into the population buffers
 unpack kernels and no staging copies.
 
 Schedule of one fused step (pull scheme, state = post-collision populations f*):
-  1. stream-collide the two boundary planes (1 and nz_local) -> they are what the neighbours need;
-  2. start the exchange of those planes on the communication stream: the populations with
-     e_z = -1 of plane 1 go to the lower neighbour's upper ghost plane, those with e_z = +1 of
-     plane nz_local to the upper neighbour's lower ghost plane (5 + 5 of 19 for D3Q19);
-  3. stream-collide the interior planes on the compute stream while the exchange is in flight
-     (interior nodes never read a ghost plane);
-  4. the compute stream waits for the exchange before the next step's boundary planes.
+  communication stream (high priority)          compute stream
+  1. stream-collide the two boundary planes     3. stream-collide the interior planes
+     (1 and nz_local): what the neighbours need    (interior nodes never read a ghost plane)
+  2. pack the crossing populations (e_z = -1 of
+     plane 1, e_z = +1 of plane nz_local: 5 + 5
+     of 19 for D3Q19) into one buffer each, send
+     them to the lower / upper neighbour, receive
+     theirs, unpack into the ghost planes
+  4. both streams join before the next step.
 There is no collective on the step path; only observables use an all-reduce.
 """
 from timeit import default_timer as timer
@@ -93,7 +95,7 @@ class SlabSimulation:
     """
 
     def __init__(self, flow, collision, slab: ZSlab, reporter=None, engine=None, group=None,
-                 overlap: bool = True):
+                 overlap: bool = True, comm_priority: int = -1):
         if flow.boundaries:
             raise LettuceException("the slab driver handles periodic flows (no boundaries)")
         if list(flow.resolution) != slab.extended_resolution:
@@ -123,7 +125,13 @@ class SlabSimulation:
         self.f_next = torch.empty_like(self.f)
         flow.f = None                       # the extended slab is not needed any more
         flow._f_next = None
-        self._comm = torch.cuda.Stream(device=self.context.device) if self.overlap else None
+        # one contiguous message per direction: [n_crossing, ny, nx]
+        shape = [len(self.up), ny, nx]
+        new = lambda: torch.empty(shape, dtype=self.f.dtype, device=self.f.device)   # noqa: E731
+        self._send_up, self._send_down, self._recv_up, self._recv_down = new(), new(), new(), new()
+        self._comm = (torch.cuda.Stream(device=self.context.device, priority=comm_priority)
+                      if self.overlap else None)
+        self._host_transport = (slab.world_size > 1 and dist.get_backend(group) != "nccl")
 
     # ---- views ---------------------------------------------------------------------------------
     def local_f(self) -> torch.Tensor:
@@ -146,48 +154,80 @@ class SlabSimulation:
         return torch.cat(parts, dim=3) if parts is not None else None
 
     # ---- halo exchange -------------------------------------------------------------------------
-    def _exchange(self, buf: torch.Tensor):
-        """Fill the ghost planes of ``buf`` (post-collision populations) from the neighbours.
-        Returns the outstanding requests (empty when done synchronously)."""
-        nzl, s = self.nzl, self.slab
-        if s.world_size == 1:
-            buf[self.down, nzl + 1] = buf[self.down, 1]
-            buf[self.up, 0] = buf[self.up, nzl]
-            return []
-        ops = []
-        for q in self.down:     # towards -z: my plane 1 -> prev's upper ghost
-            ops.append(dist.P2POp(dist.isend, buf[q, 1], s.prev, self.group, tag=q))
-            ops.append(dist.P2POp(dist.irecv, buf[q, nzl + 1], s.next, self.group, tag=q))
-        for q in self.up:       # towards +z: my top plane -> next's lower ghost
-            ops.append(dist.P2POp(dist.isend, buf[q, nzl], s.next, self.group, tag=100 + q))
-            ops.append(dist.P2POp(dist.irecv, buf[q, 0], s.prev, self.group, tag=100 + q))
-        return dist.batch_isend_irecv(ops)
+    def _pack(self, buf, plane, direction, out):
+        if hasattr(self.engine, "pack"):
+            self.engine.pack(buf, plane, direction, out)
+        else:
+            out.copy_(buf[self.up if direction > 0 else self.down, plane])
 
-    @staticmethod
-    def _wait(reqs):
-        for r in reqs:
-            r.wait()
+    def _unpack(self, buf, plane, direction, src):
+        if hasattr(self.engine, "unpack"):
+            self.engine.unpack(buf, plane, direction, src)
+        else:
+            buf[self.up if direction > 0 else self.down, plane] = src
+
+    def _exchange(self, buf: torch.Tensor):
+        """Fill the ghost planes of ``buf`` (post-collision populations) from the neighbours:
+        the e_z = -1 populations of my plane 1 go to the lower neighbour's upper ghost plane, the
+        e_z = +1 populations of my top plane to the upper neighbour's lower ghost plane.  One
+        packed message per direction.  Returns a callable that completes the exchange (waits
+        for the transfers and unpacks)."""
+        nzl, s = self.nzl, self.slab
+        self._pack(buf, 1, -1, self._send_down)
+        self._pack(buf, nzl, +1, self._send_up)
+        if s.world_size == 1:
+            recv_down, recv_up, reqs = self._send_down, self._send_up, []
+        else:
+            recv_down, recv_up = self._recv_down, self._recv_up
+            if self._host_transport and buf.is_cuda:
+                # gloo moves device tensors from the host side without stream semantics (only
+                # used by tests that put two ranks on one GPU): make the packed data visible
+                torch.cuda.current_stream().synchronize()
+            ops = [dist.P2POp(dist.isend, self._send_down, s.prev, self.group, tag=1),
+                   dist.P2POp(dist.irecv, recv_down, s.next, self.group, tag=1),
+                   dist.P2POp(dist.isend, self._send_up, s.next, self.group, tag=2),
+                   dist.P2POp(dist.irecv, recv_up, s.prev, self.group, tag=2)]
+            reqs = dist.batch_isend_irecv(ops)
+
+        def finish():
+            for r in reqs:
+                r.wait()
+            if reqs and self._host_transport and buf.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            self._unpack(buf, nzl + 1, -1, recv_down)
+            self._unpack(buf, 0, +1, recv_up)
+        return finish
 
     # ---- stepping --------------------------------------------------------------------------------
+    def _boundary_planes(self, cur, nxt, tau):
+        if self.nzl > 1 and hasattr(self.engine, "stream_collide_plane_pair"):
+            self.engine.stream_collide_plane_pair(cur, nxt, tau, 1, self.nzl)   # one launch
+            return
+        self.engine.stream_collide_planes(cur, nxt, tau, 1, 2)
+        if self.nzl > 1:
+            self.engine.stream_collide_planes(cur, nxt, tau, self.nzl, self.nzl + 1)
+
     def _fused_step(self, cur, nxt, tau):
+        """One stream-collide of the slab.  With overlap the two boundary planes, the halo packing,
+        the transfers and the unpacking run on the (high-priority) communication stream while the
+        compute stream does the interior planes; both only read ``cur`` and write disjoint planes
+        of ``nxt``.  The streams join before the next step."""
         eng, nzl = self.engine, self.nzl
-        eng.stream_collide_planes(cur, nxt, tau, 1, 2)
-        if nzl > 1:
-            eng.stream_collide_planes(cur, nxt, tau, nzl, nzl + 1)
         if self.overlap:
             compute = torch.cuda.current_stream()
-            self._comm.wait_stream(compute)
+            self._comm.wait_stream(compute)          # previous step complete (it read nxt)
             with torch.cuda.stream(self._comm):
-                reqs = self._exchange(nxt)
-                self._wait(reqs)              # orders the comm stream behind the transfers
-            if nzl > 2:
-                eng.stream_collide_planes(cur, nxt, tau, 2, nzl)   # overlaps with the exchange
-            compute.wait_stream(self._comm)
-        else:
-            reqs = self._exchange(nxt)
+                self._boundary_planes(cur, nxt, tau)
+                self._exchange(nxt)()
             if nzl > 2:
                 eng.stream_collide_planes(cur, nxt, tau, 2, nzl)
-            self._wait(reqs)
+            compute.wait_stream(self._comm)
+        else:
+            self._boundary_planes(cur, nxt, tau)
+            finish = self._exchange(nxt)
+            if nzl > 2:
+                eng.stream_collide_planes(cur, nxt, tau, 2, nzl)
+            finish()
 
     def _advance(self, n: int):
         """n whole steps: collide, exchange, (n-1) x fused, stream -- as lt_run does on one GPU."""
@@ -196,7 +236,7 @@ class SlabSimulation:
         cur, nxt = self.f, self.f_next
         eng.collide_planes(cur, nxt, tau, 1, nzl + 1)
         cur, nxt = nxt, cur
-        self._wait(self._exchange(cur))
+        self._exchange(cur)()
         for _ in range(n - 1):
             self._fused_step(cur, nxt, tau)
             cur, nxt = nxt, cur

@@ -138,6 +138,49 @@ int check_boundary(const lt_plan *p, const lt_boundary_desc &b, int n_abb_before
 
 // Nontemporal stores pay off when the two population buffers cannot stay in the caches
 // (32 MiB L2 + 256 MiB Infinity Cache); small grids keep cached stores.
+// populations whose velocity component along the slowest memory axis equals `dir`
+template <class S>
+lt::QList crossing_of(int logical_axis, int dir) {
+  lt::QList l;
+  l.n = 0;
+  for (int q = 0; q < S::Q; ++q)
+    if (S::E[q][logical_axis] == dir && l.n < 9) l.q[l.n++] = q;
+  return l;
+}
+
+lt::QList crossing(const lt_plan *p, int dir) {
+  const int axis = p->unit.d == 2 ? 0 : (p->desc.layout == LT_LAYOUT_REFERENCE ? 0 : 2);
+  switch (p->desc.stencil) {
+    case LT_D2Q9: return crossing_of<lt::D2Q9>(axis, dir);
+    case LT_D3Q19: return crossing_of<lt::D3Q19>(axis, dir);
+    default: return crossing_of<lt::D3Q27>(axis, dir);
+  }
+}
+
+int pack(lt_plan *p, bool do_pack, void *f, long long plane, int dir, void *buf, void *stream) {
+  if (!p || !f || !buf) return fail(LT_ERR_INVALID, "null argument");
+  if (dir != 1 && dir != -1) return fail(LT_ERR_INVALID, "direction %d (must be +1 or -1)", dir);
+  if (plane < 0 || plane >= p->n2) return fail(LT_ERR_INVALID, "plane %lld outside [0, %d)", plane, p->n2);
+  const lt::QList ql = crossing(p, dir);
+  const int plane_nodes = p->n0 * p->n1;
+  const long long off = plane * plane_nodes;
+  const unsigned grid = (plane_nodes + lt::kThreads - 1) / lt::kThreads;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (p->desc.dtype == LT_F32) {
+    if (do_pack) hipLaunchKernelGGL((lt::plane_pack_kernel<float, true>), dim3(grid), dim3(lt::kThreads), 0, s,
+                                    (float *)f, (float *)buf, p->N, off, plane_nodes, ql);
+    else hipLaunchKernelGGL((lt::plane_pack_kernel<float, false>), dim3(grid), dim3(lt::kThreads), 0, s,
+                            (float *)f, (float *)buf, p->N, off, plane_nodes, ql);
+  } else {
+    if (do_pack) hipLaunchKernelGGL((lt::plane_pack_kernel<double, true>), dim3(grid), dim3(lt::kThreads), 0, s,
+                                    (double *)f, (double *)buf, p->N, off, plane_nodes, ql);
+    else hipLaunchKernelGGL((lt::plane_pack_kernel<double, false>), dim3(grid), dim3(lt::kThreads), 0, s,
+                            (double *)f, (double *)buf, p->N, off, plane_nodes, ql);
+  }
+  LT_HIP(hipGetLastError());
+  return LT_OK;
+}
+
 int resolve_tune(const lt_plan *p, int wide) {
   if (wide) return p->tune < 0 ? 0 : p->tune;
   if (p->tune == 0 || p->tune == 2) return p->tune;
@@ -146,7 +189,7 @@ int resolve_tune(const lt_plan *p, int wide) {
 }
 
 int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long pb, long long pe,
-         void *stream) {
+         void *stream, long long stride = 1) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (!in || !out) return fail(LT_ERR_INVALID, "null population buffer");
   if (in == out) return fail(LT_ERR_INVALID, "in-place operation is not supported (in == out)");
@@ -163,7 +206,7 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   memset(&a, 0, sizeof a);
   a.in = in; a.out = out;
   a.n0 = p->n0; a.n1 = p->n1; a.n2 = p->n2;
-  a.p_begin = (int)pb; a.planes = (int)(pe - pb);
+  a.p_begin = (int)pb; a.planes = (int)((pe - pb + stride - 1) / stride); a.p_stride = (int)stride;
   a.wrap2 = p->desc.ghost_planes ? 0 : 1;
   a.tau = tau > 0.0 ? tau : 1.0;
   a.node = p->node; a.nsm_bits = p->nsm_bits; a.bt = p->bt; a.nb = p->desc.n_boundaries;
@@ -363,6 +406,12 @@ int lt_stream_collide_planes(lt_plan *p, const void *f, void *o, double tau, int
   return step(p, lt::kFused, f, o, tau, b, e, s);
 }
 
+int lt_stream_collide_plane_pair(lt_plan *p, const void *f, void *o, double tau, int64_t first,
+                                 int64_t second, void *s) {
+  if (second <= first) return fail(LT_ERR_INVALID, "plane pair (%lld, %lld)", (long long)first, (long long)second);
+  return step(p, lt::kFused, f, o, tau, first, second + 1, s, second - first);
+}
+
 int lt_run(lt_plan *p, void *a, void *b, double tau, int64_t n, void *s, int32_t *r) {
   return run(p, false, a, b, tau, n, s, r);
 }
@@ -411,6 +460,20 @@ const char *lt_plan_kernel_name(lt_plan *p) {
   const char *n = p->unit.name(a);
   snprintf(p->kernel_name, sizeof p->kernel_name, "%s", n ? n : "");
   return p->kernel_name;
+}
+
+int lt_slab_crossing(lt_plan *p, int32_t direction, int32_t *q_out, int32_t *n_out) {
+  if (!p || !n_out) return fail(LT_ERR_INVALID, "null argument");
+  const lt::QList ql = crossing(p, direction);
+  *n_out = ql.n;
+  if (q_out) for (int k = 0; k < ql.n; ++k) q_out[k] = ql.q[k];
+  return LT_OK;
+}
+int lt_slab_pack(lt_plan *p, const void *f, int64_t plane, int32_t direction, void *buf, void *s) {
+  return pack(p, true, const_cast<void *>(f), plane, direction, buf, s);
+}
+int lt_slab_unpack(lt_plan *p, void *f, int64_t plane, int32_t direction, const void *buf, void *s) {
+  return pack(p, false, f, plane, direction, const_cast<void *>(buf), s);
 }
 
 int lt_probe_copy(void *dst, const void *src, int64_t n_bytes, int32_t cache_policy,

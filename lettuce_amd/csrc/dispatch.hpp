@@ -12,7 +12,8 @@ struct StepArgs {
   const void *in;
   void *out;
   int n0, n1, n2;        // memory extents (n2 incl. ghost planes)
-  int p_begin, planes;   // a2 plane range of this launch
+  int p_begin, planes;   // a2 planes of this launch: p_begin + i * p_stride, i < planes
+  int p_stride;
   int wrap2;
   double tau;
   const unsigned char *node;

@@ -53,6 +53,7 @@ struct KParams {
   int n0, n1, n2;            // memory extents; n2 includes ghost planes
   int nv0;                   // n0 / VEC
   int p_begin;               // first a2 plane of this launch
+  int p_stride;              // distance between consecutive planes of this launch (normally 1)
   int wrap2;                 // periodic wrap along a2 (0 with ghost planes)
   long long N;               // n0*n1*n2 = stride between populations
   unsigned nvec_total;       // threads doing work: nv0 * n1 * planes
@@ -507,7 +508,7 @@ __device__ __forceinline__ void lbm_body(const KParams<T> &p) {
   const int c0 = (int)(v - rowid * (unsigned)p.nv0) * VEC;
   const int r2 = (int)(rowid / (unsigned)p.n1);
   const int c1 = (int)(rowid - (unsigned)r2 * (unsigned)p.n1);
-  const int c2 = p.p_begin + r2;
+  const int c2 = p.p_begin + r2 * p.p_stride;
   const Coord c = make_coord(p, c0, c1, c2);
   const unsigned own = (unsigned)(c2 * p.n1 + c1) * (unsigned)p.n0 + (unsigned)c0;
 
@@ -674,6 +675,29 @@ static __global__ void __launch_bounds__(kThreads) finish_sum_kernel(const doubl
   for (int i = threadIdx.x; i < n; i += kThreads) acc += partial[i];
   const double s = block_sum(acc);
   if (threadIdx.x == 0) *out = s;
+}
+
+// halo pack / unpack of the slab driver: the populations that cross a z cut (5 of 19, 9 of 27)
+// of one a2 plane <-> one contiguous buffer [n][n1*n0], so that a ghost exchange is a single
+// send and a single receive per direction
+struct QList {
+  int n;
+  int q[9];
+};
+template <typename T, bool PACK>
+__global__ void __launch_bounds__(kThreads) plane_pack_kernel(T *__restrict__ f, T *__restrict__ buf,
+                                                              long long N, long long plane_off,
+                                                              int plane_nodes, QList ql) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= plane_nodes) return;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    if (k < ql.n) {
+      T *slot = f + (long long)ql.q[k] * N + plane_off + i;
+      if (PACK) buf[(long long)k * plane_nodes + i] = *slot;
+      else *slot = buf[(long long)k * plane_nodes + i];
+    }
+  }
 }
 
 // node descriptor byte + sparse streaming-mask bits from the reference's two mask tensors

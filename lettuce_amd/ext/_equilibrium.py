@@ -24,8 +24,17 @@ class QuadraticEquilibrium(Equilibrium):
         rho = flow.rho() if rho is None else rho
         u = flow.u() if u is None else u
         st = flow.torch_stencil
-        e_dot_u = torch.tensordot(st.e, u, dims=1)
-        u_sq = flow.einsum("d,d->", [u, u])
+        grid = list(flow.resolution)
+        if (flow.context.use_native and torch.is_tensor(rho) and list(rho.shape) == [1] + grid
+                and list(u.shape) == [st.d] + grid and flow._engine_plan(flow.f) is not None):
+            # whole-field feq(rho, u) on a native context: the engine's equilibrium kernel
+            return flow._engine_plan(flow.f).equilibrium(rho.to(flow.f.dtype), u.contiguous())
+        if u.is_cuda and u.dim() > 1:
+            from .._flow import local_contract
+            e_dot_u = local_contract(st.e, u)
+        else:
+            e_dot_u = torch.tensordot(st.e, u, dims=1)
+        u_sq = (u * u).sum(dim=0) if u.is_cuda else flow.einsum("d,d->", [u, u])
         bracket = (2 * e_dot_u - u_sq) / (2 * st.cs ** 2) + 0.5 * (e_dot_u / (st.cs ** 2)) ** 2 + 1
         return flow.einsum("q,q->q", [st.w, rho * bracket])
 

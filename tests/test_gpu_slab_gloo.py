@@ -1,0 +1,49 @@
+"""Two ranks sharing the one GPU of the test box, gloo backend: the real HIP slab kernels and the
+real point-to-point ghost-plane exchange code (only the transport differs from RCCL, which
+cannot put two ranks on one device) must reproduce the single-domain oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, res, steps, dtype_name, overlap, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import lettuce_amd as lt
+    ctx = lt.Context("cuda:0", getattr(torch, dtype_name), use_native=True)
+    slab = lt.ZSlab(res)
+    flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 400, 0.1, lt.D3Q19(), slab=slab)
+    sim = lt.SlabSimulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
+                            overlap=overlap)
+    sim(steps)
+    f1 = sim.gather_f()
+    ke = sim.kinetic_energy_pu()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "out.npz"), f1=f1.cpu().numpy(), ke=ke)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False], ids=["overlap", "serial"])
+def test_two_ranks_one_gpu(tmp_path, overlap):
+    from oracle import lettuce_oracle as orc
+    res, steps = [32, 16, 16], 6
+    port = 29700 + (os.getpid() % 1000) + int(overlap)
+    mp.spawn(_worker, args=(2, port, res, steps, "float64", overlap, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "out.npz")
+    ref = orc.taylor_green(res, 400, 0.1, "D3Q19", torch.float64)
+    ref.step(steps)
+    np.testing.assert_allclose(got["f1"], ref.f.numpy(), rtol=0, atol=1e-13)
+    assert float(got["ke"]) == pytest.approx(float(orc.kinetic_energy_pu(ref.f, ref.lat, ref.units)), rel=1e-11)
