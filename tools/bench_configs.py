@@ -1,0 +1,59 @@
+"""MLUPS of the other BASELINE.json configurations through the lettuce-style API (single GPU):
+cfg1 TGV2D D2Q9 128^2 fp64, cfg4 Obstacle3D D3Q27 256^3 KBC fp32 (inlet + ABB outlet + sphere
+bounce-back), cfg5's per-GPU slab (periodic shear D3Q19 384x384x96 fp64).  One JSON line each."""
+import sys, os, json, time, io, contextlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import lettuce_amd as lt
+
+def timed(sim, warm, steps):
+    sim(warm); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sim._native.fused_events = (e0, e1)
+    t0 = time.perf_counter(); sim(steps); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    fused_ms = e0.elapsed_time(e1) / (steps - 1)
+    sim._native.fused_events = None
+    return dt, fused_ms
+
+def report(name, flow, sim, dt, fused_ms, steps, bytes_per_node):
+    n = 1
+    for r in flow.resolution: n *= r
+    gbs = bytes_per_node * n / (fused_ms * 1e-3) / 1e9
+    print(json.dumps({"config": name, "resolution": flow.resolution, "steps": steps,
+                      "mlups_wall": round(steps * n / dt / 1e6, 1), "fused_kernel_ms": round(fused_ms, 5),
+                      "fused_GBps": round(gbs, 1), "frac_of_8TBs": round(gbs / 8000, 4),
+                      "bytes_per_node": bytes_per_node, "kernel": sim._native.plan.kernel_name()}), flush=True)
+
+def main():
+    which = sys.argv[1:] or ["cfg1", "cfg4", "cfg5", "cfg4bgk"]
+    if "cfg1" in which:
+        ctx = lt.Context("cuda:0", torch.float64, True)
+        flow = lt.TaylorGreenVortex(ctx, [128, 128], 100, 0.05, lt.D2Q9())
+        sim = lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])
+        dt, ms = timed(sim, 100, 1000)
+        report("cfg1 TGV2D D2Q9 128^2 BGK fp64 (launch-bound)", flow, sim, dt, ms, 1000, 144)
+        e = float(lt.IncompressibleKineticEnergy(flow)())
+        print(json.dumps({"cfg1_energy_after_1100_steps": e}), flush=True)
+    for tag, coll in (("cfg4", "kbc"), ("cfg4bgk", "bgk")):
+        if tag not in which: continue
+        ctx = lt.Context("cuda:0", torch.float32, True)
+        flow = lt.Obstacle(ctx, [256, 256, 256], 100, 0.1, domain_length_x=4, stencil=lt.D3Q27())
+        x, y, z = flow.grid
+        flow.mask = ((x - 1) ** 2 + (y - 2) ** 2 + (z - 2) ** 2) < 0.5 ** 2
+        flow.initialize()
+        collision = lt.KBCCollision() if coll == "kbc" else lt.BGKCollision(flow.units.relaxation_parameter_lu)
+        sim = lt.Simulation(flow, collision, [])
+        dt, ms = timed(sim, 10, 100)
+        report(f"cfg4 Obstacle3D D3Q27 256^3 {coll.upper()} fp32, inlet+ABB outlet+sphere BB", flow, sim, dt, ms, 100, 217)
+        u = flow.u()
+        print(json.dumps({"finite": bool(torch.isfinite(flow.f).all()), "umax_lu": float(u.abs().max())}), flush=True)
+        del sim, flow
+        torch.cuda.empty_cache()
+    if "cfg5" in which:
+        ctx = lt.Context("cuda:0", torch.float64, True)
+        flow = lt.DoublyPeriodicShear3D(ctx, [384, 384, 96], 10000, 0.1)
+        sim = lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])
+        dt, ms = timed(sim, 10, 100)
+        report("cfg5 per-GPU slab: periodic shear D3Q19 384x384x96 BGK fp64", flow, sim, dt, ms, 100, 304)
+
+main()
