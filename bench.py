@@ -27,6 +27,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -64,6 +66,25 @@ def cpu_baseline(size, steps):
                       f"{steps} steps after 1 warm-up step, {threads} threads"}
 
 
+def copy_ceiling(device, nbytes=1 << 30, iters=20):
+    """This device's plain streaming-copy rate (16 B per lane, read + write bytes counted), the
+    practical HBM ceiling next to the 8 TB/s spec number."""
+    from lettuce_amd._native import probe_copy
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    best = 0.0
+    for policy in (0, 3):                      # cached, nontemporal
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        probe_copy(dst, src, policy)
+        e0.record()
+        for _ in range(iters):
+            probe_copy(dst, src, policy)
+        e1.record()
+        torch.cuda.synchronize(device)
+        best = max(best, 2 * nbytes * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    return best
+
+
 def traffic_from_profile(kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/traffic.json, produced by tools/pmc_traffic.py on the GPU box); null if absent."""
@@ -71,8 +92,11 @@ def traffic_from_profile(kernel_name):
     try:
         with open(path) as fh:
             table = json.load(fh)
+        want = kernel_name.lower().replace(" ", "")
         for row in table.get("kernels", []):
-            if row.get("workload") == "tgv3d_d3q19_bgk_f32_256" and row.get("hbm_bytes_per_launch"):
+            have = row.get("kernel", "").lower().replace(" ", "")
+            if (row.get("workload") == "tgv3d_d3q19_bgk_f32_256" and want in have
+                    and row.get("hbm_bytes_per_launch")):
                 return row["hbm_bytes_per_launch"]
     except (OSError, ValueError):
         pass
@@ -155,6 +179,9 @@ def main():
                     "kernel": kernel, "avg_launch_ms": round(fused_ms, 5),
                     "algorithmic_bytes_per_launch": BYTES_PER_NODE * nodes_per_rank,
                     "launches_timed": args.steps - 1}
+        ceiling = copy_ceiling(device)
+        roofline["copy_ceiling_GBps"] = round(ceiling, 1)
+        roofline["frac_of_copy_ceiling"] = round(achieved / ceiling, 4)
     elif distributed:
         # per-rank fused-kernel rate is not separable from the exchange here; report the
         # effective whole-step rate of one rank against the same algorithmic bytes

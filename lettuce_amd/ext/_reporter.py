@@ -16,7 +16,7 @@ from .._simulation import Reporter
 from ..util import torch_gradient
 
 __all__ = ["Observable", "ObservableReporter", "MaximumVelocity", "IncompressibleKineticEnergy",
-           "Enstrophy", "Mass"]
+           "Enstrophy", "Mass", "ErrorReporter"]
 
 
 class Observable(ABC):
@@ -105,3 +105,36 @@ class ObservableReporter(Reporter):
             self.out.append(entry)
         else:
             print(*entry, file=self.out)
+
+
+class ErrorReporter(Reporter):
+    """L2 errors of u and p (physical units) against an analytic solution, e.g.
+    ``flow.analytic_solution`` of the 2-D Taylor-Green vortex; used by the convergence check
+    ("next" row F4; lettuce/ext/_reporter/error_reporter.py:9-48, lettuce/cli.py:128-180)."""
+
+    def __init__(self, analytical_solution, interval=1, out=sys.stdout):
+        Reporter.__init__(self, interval)
+        self.analytical_solution = analytical_solution
+        self.out = [] if out is None else out
+        if not isinstance(self.out, list):
+            print("#error_u         error_p", file=self.out)
+
+    def __call__(self, simulation: "Simulation"):
+        flow = simulation.flow
+        if flow.i % self.interval != 0:
+            return
+        p_ref, u_ref = self.analytical_solution(t=simulation.units.convert_time_to_pu(flow.i))
+        p_ref = flow.context.convert_to_tensor(p_ref)
+        u_ref = flow.context.convert_to_tensor(u_ref)
+        p, u = flow.p_pu, flow.u_pu
+        d = flow.stencil.d
+        nodes = 1
+        for n in p.size():
+            nodes *= n
+        scale = (nodes ** (1 / d)) ** (d / 2)
+        err_u = (torch.norm(u - u_ref) / scale).item()
+        err_p = (torch.norm(p - p_ref) / scale).item()
+        if isinstance(self.out, list):
+            self.out.append([err_u, err_p])
+        else:
+            print(err_u, err_p, file=self.out)

@@ -263,3 +263,44 @@ def test_slab_driver_single_rank_on_gpu():
         ref = orc.taylor_green(rs, 400, 0.1, "D3Q27", torch.float32, "kbc")
         sim(5); ref.step(5)
         np.testing.assert_allclose(sim.gather_f().cpu().numpy(), ref.f.numpy(), rtol=0, atol=2e-6)
+
+
+def test_cfg1_simplest_tgv_energy_anchors():
+    """BASELINE configs[0] = examples/00_simplest_TGV.py (D2Q9 128^2 fp64 Re 100 Ma 0.05, BGK,
+    1000 steps) on the HIP engine against the reference CPU path: populations after 100 steps
+    (golden) and the kinetic energies the survey recorded from the reference at steps
+    0 / 100 / 500 / 1000."""
+    g = golden("tgv2d_d2q9_bgk_128_f64")
+    flow = lt.TaylorGreenVortex(gpu("f64"), 128, 100, 0.05, lt.D2Q9())
+    assert flow.units.relaxation_parameter_lu == pytest.approx(0.610851251684408, rel=1e-14)
+    out = []
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setattr("sys.stdout", io.StringIO())
+        rep = lt.ObservableReporter(lt.IncompressibleKineticEnergy(flow), interval=100, out=out)
+    sim = lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [rep])
+    sim(100)
+    np.testing.assert_allclose(flow.f.cpu().numpy(), g["f100"], rtol=0, atol=1e-12)
+    sim(900)
+    energy = {row[0]: row[2] for row in out}
+    anchors = {0: 9.86960440108935, 100: 9.52452318761345, 500: 8.26054982612006, 1000: 6.91369866821884}
+    for i, e in anchors.items():
+        assert energy[i] == pytest.approx(e, rel=1e-10)
+    assert float(flow.f.sum().cpu()) == pytest.approx(16384.0, rel=1e-12)      # mass
+
+
+def test_convergence_order_tgv2d():
+    """`lettuce convergence` (lettuce/cli.py:128-180) on the HIP engine: diffusive scaling on
+    the 2-D Taylor-Green vortex gives second order in u and first order in p."""
+    c = gpu("f64")
+    errors = []
+    for res in (16, 32, 64, 128):
+        flow = lt.TaylorGreenVortex(c, [res] * 2, reynolds_number=10000, mach_number=8 / res)
+        rep = lt.ErrorReporter(flow.analytic_solution, interval=1, out=None)
+        sim = lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [rep])
+        sim(10 * res)
+        errors.append(np.mean(np.abs(rep.out), axis=0))
+    order_u = np.log2(errors[-2][0] / errors[-1][0])
+    order_p = np.log2(errors[-2][1] / errors[-1][1])
+    # the reference accepts factor/2 within 0.1 of 2 (u) and of 1 (p)
+    assert 1.8 < 2 ** order_u / 2 < 2.2, (errors, order_u)
+    assert 0.8 < 2 ** order_p / 2 < 1.2, (errors, order_p)

@@ -269,6 +269,15 @@ def test_library_exports_every_declared_symbol():
     bad.shape[0] = bad.shape[1] = bad.shape[2] = 8
     assert lib.lt_plan_create(_native.ctypes.byref(bad), _native.ctypes.byref(handle)) == 2
     assert b"KBC" in lib.lt_last_error()
+    # empty and oversized grids are refused with a message (no HIP call has happened yet)
+    bad.collision = 1
+    bad.shape[2] = 0
+    assert lib.lt_plan_create(_native.ctypes.byref(bad), _native.ctypes.byref(handle)) == 1
+    assert b"shape[2]" in lib.lt_last_error()
+    bad.shape[0], bad.shape[1], bad.shape[2] = 2048, 2048, 512            # 2^31 nodes
+    assert lib.lt_plan_create(_native.ctypes.byref(bad), _native.ctypes.byref(handle)) == 2
+    assert b"2^31" in lib.lt_last_error()
+    assert lib.lt_plan_destroy(None) == 0
 
 
 def test_native_context_never_falls_back(monkeypatch):
