@@ -201,9 +201,9 @@ int lt_plan_set_shift_policy(lt_plan *plan, int32_t policy);
  * and grid cap as lt_plan_set_tuning.  bench.py uses it to measure this device's copy ceiling. */
 int lt_probe_copy(void *dst_dev, const void *src_dev, int64_t n_bytes, int32_t cache_policy,
                   int32_t max_blocks, void *stream);
-/* Tuning knobs.  cache_policy: -1 = automatic (nontemporal stores when the populations exceed
+/* Tuning knobs.  cache_policy: -1 = automatic (nontemporal accesses when the populations exceed
  * the caches), else bit 0 = nontemporal loads, bit 1 = nontemporal stores (the one-node-per-
- * thread kernels exist for 0 and 2).  max_blocks > 0 caps the grid (grid-stride loop).
+ * thread kernels exist for 0 and 3).  max_blocks > 0 caps the grid (grid-stride loop).
  * wide != 0 switches the hot kernel (fused, BGK, no masks) to its 16-byte-per-lane A/B variant,
  * whose shift handling lt_plan_set_shift_policy selects. */
 int lt_plan_set_tuning(lt_plan *plan, int32_t cache_policy, int32_t max_blocks, int32_t wide);

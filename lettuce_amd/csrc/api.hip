@@ -136,7 +136,7 @@ int check_boundary(const lt_plan *p, const lt_boundary_desc &b, int n_abb_before
   }
 }
 
-// Nontemporal stores pay off when the two population buffers cannot stay in the caches
+// Nontemporal accesses pay off when the two population buffers cannot stay in the caches
 // (32 MiB L2 + 256 MiB Infinity Cache); small grids keep cached stores.
 // populations whose velocity component along the slowest memory axis equals `dir`
 template <class S>
@@ -183,9 +183,9 @@ int pack(lt_plan *p, bool do_pack, void *f, long long plane, int dir, void *buf,
 
 int resolve_tune(const lt_plan *p, int wide) {
   if (wide) return p->tune < 0 ? 0 : p->tune;
-  if (p->tune == 0 || p->tune == 2) return p->tune;
+  if (p->tune == 0 || p->tune == 3) return p->tune;
   const long long bytes = 2ll * p->unit.q * p->N * p->esize;
-  return bytes > (128ll << 20) ? 2 : 0;
+  return bytes > (128ll << 20) ? 3 : 0;
 }
 
 int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long pb, long long pe,

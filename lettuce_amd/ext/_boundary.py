@@ -124,7 +124,11 @@ class AntiBounceBackOutlet(Boundary):
         u = flow.u()
         here = tuple([slice(None)] + self.index)
         u_w = u[here] + 0.5 * (u[here] - u[tuple([slice(None)] + self.neighbor)])
-        e_dot_u = torch.einsum("cd,d...->c...", st.e[self.velocities], u_w)
+        if u_w.is_cuda:         # no BLAS on device tensors (see _flow.local_contract)
+            from .._flow import local_contract
+            e_dot_u = local_contract(st.e[self.velocities], u_w)
+        else:
+            e_dot_u = torch.einsum("cd,d...->c...", st.e[self.velocities], u_w)
         f = flow.f
         f[tuple([self._opposite_of_velocities(flow.context)] + self.index)] = (
             - flow.f[tuple([self.velocities] + self.index)]

@@ -94,7 +94,11 @@ class KBCCollision(Collision):
         rho = torch.sum(g, dim=0)
 
         def m(a, b):
-            return torch.einsum("q,q...->...", e[:, a] * e[:, b], g) / rho
+            coeff = e[:, a] * e[:, b]
+            if g.is_cuda:       # no BLAS on device tensors (see _flow.local_contract)
+                from .._flow import local_contract
+                return local_contract(coeff[None, :], g)[0] / rho
+            return torch.einsum("q,q...->...", coeff, g) / rho
 
         return rho, m
 

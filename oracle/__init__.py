@@ -1,0 +1,1 @@
+"""CPU oracle of the LBM hot path -- test infrastructure only (see lettuce_oracle.py)."""

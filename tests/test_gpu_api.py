@@ -304,3 +304,23 @@ def test_convergence_order_tgv2d():
     # the reference accepts factor/2 within 0.1 of 2 (u) and of 1 (p)
     assert 1.8 < 2 ** order_u / 2 < 2.2, (errors, order_u)
     assert 0.8 < 2 ** order_p / 2 < 1.2, (errors, order_p)
+
+
+def test_non_native_mode_on_a_gpu_device():
+    """Context('cuda', use_native=False): the reference's whole-field torch expressions on device
+    tensors (per-node contractions evaluated without BLAS) still match the reference vectors."""
+    g = golden("obstacle3d_d3q27_kbc_f64")
+    c = lt.Context("cuda:0", torch.float64, use_native=False)
+    flow = lt.Obstacle(c, [int(r) for r in g["resolution"]], 100, 0.1, float(g["domain_length_x"]), stencil=lt.D3Q27())
+    flow.mask = g["obstacle_mask"]
+    flow.initialize()
+    sim = lt.Simulation(flow, lt.KBCCollision(), [])
+    assert sim._native is None
+    sim(2)
+    np.testing.assert_allclose(flow.f.cpu().numpy(), g["f2"], rtol=0, atol=1e-12)
+    g = golden("tgv3d_d3q19_bgk_16_f64")
+    flow = lt.TaylorGreenVortex(c, [16] * 3, 1600, 0.1, lt.D3Q19())
+    np.testing.assert_allclose(flow.f.cpu().numpy(), g["f0"], rtol=0, atol=1e-13)
+    lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])(10)
+    np.testing.assert_allclose(flow.f.cpu().numpy(), g["f10"], rtol=0, atol=1e-12)
+    assert float(lt.IncompressibleKineticEnergy(flow)()) == pytest.approx(float(g["energy_pu"][1]), rel=1e-10)

@@ -16,7 +16,7 @@ template <typename T, class S, int VEC, int SHIFT, int TUNE, int MINW>
 static int go(const void *in, void *out, int n0, int n1, int n2, double tau, int cap, int tpb, hipStream_t st) {
   KParams<T> p;
   p.in = (const T *)in; p.out = (T *)out;
-  p.n0 = n0; p.n1 = n1; p.n2 = n2; p.nv0 = n0 / VEC; p.p_begin = 0; p.wrap2 = 1;
+  p.n0 = n0; p.n1 = n1; p.n2 = n2; p.nv0 = n0 / VEC; p.p_begin = 0; p.p_stride = 1; p.wrap2 = 1;
   p.N = (long long)n0 * n1 * n2;
   p.nvec_total = (unsigned)((long long)p.nv0 * n1 * n2);
   p.tau_inv = (T)(1.0 / tau); p.beta = p.inv_beta = 0;
@@ -28,6 +28,58 @@ static int go(const void *in, void *out, int n0, int n1, int n2, double tau, int
   hipLaunchKernelGGL((exp_kernel<T, S, VEC, SHIFT, TUNE, MINW>), dim3(grid), dim3(tpb), 0, st, p);
   return (int)hipGetLastError();
 }
+
+// NODES independent nodes per thread, each `chunk` apart (not adjacent): more loads in flight per
+// wave at scalar-access register cost.
+template <typename T, class S, int NODES, int TUNE, int MINW>
+__global__ void __launch_bounds__(512, MINW) multi_kernel(const KParams<T> p) {
+  const unsigned chunk = gridDim.x * blockDim.x;
+  const unsigned v0 = blockIdx.x * blockDim.x + threadIdx.x;
+  T f[NODES][S::Q][1];
+  unsigned own[NODES];
+#pragma unroll
+  for (int n = 0; n < NODES; ++n) {
+    const unsigned v = v0 + n * chunk;
+    if (v < p.nvec_total) {
+      const unsigned rowid = v / (unsigned)p.nv0;
+      const int c0 = (int)(v - rowid * (unsigned)p.nv0);
+      const int r2 = (int)(rowid / (unsigned)p.n1);
+      const int c1 = (int)(rowid - (unsigned)r2 * (unsigned)p.n1);
+      const Coord c = make_coord(p, c0, c1, r2);
+      own[n] = (unsigned)(r2 * p.n1 + c1) * (unsigned)p.n0 + (unsigned)c0;
+      gather<T, S, 0, true, 1, 0, (TUNE & 1) != 0>(p, c, f[n]);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NODES; ++n) {
+    const unsigned v = v0 + n * chunk;
+    if (v < p.nvec_total) {
+      collide_bgk<T, S, 0, 1, 0>(f[n], p.tau_inv);
+      static_for<S::Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        vstore<T, 1, (TUNE & 2) != 0>(p.out + (long long)q * p.N + own[n], f[n][q]);
+      });
+    }
+  }
+}
+
+template <typename T, class S, int NODES, int TUNE, int MINW>
+static int go_multi(const void *in, void *out, int n0, int n1, int n2, double tau, int tpb, hipStream_t st) {
+  KParams<T> p;
+  p.in = (const T *)in; p.out = (T *)out;
+  p.n0 = n0; p.n1 = n1; p.n2 = n2; p.nv0 = n0; p.p_begin = 0; p.p_stride = 1; p.wrap2 = 1;
+  p.N = (long long)n0 * n1 * n2;
+  p.nvec_total = (unsigned)p.N;
+  p.tau_inv = (T)(1.0 / tau); p.beta = p.inv_beta = 0;
+  p.node = nullptr; p.nsm_bits = nullptr; p.bt = nullptr; p.nb = 0;
+  if (tpb <= 0) tpb = 256;
+  const unsigned per_block = tpb * NODES;
+  const unsigned grid = (p.nvec_total + per_block - 1) / per_block;
+  hipLaunchKernelGGL((multi_kernel<T, S, NODES, TUNE, MINW>), dim3(grid), dim3(tpb), 0, st, p);
+  return (int)hipGetLastError();
+}
+#define M(ID, TT, SS, NODES, TUNE, MINW) \
+  case ID: return go_multi<TT, SS, NODES, TUNE, MINW>(in, out, n0, n1, n2, tau, tpb, (hipStream_t)stream);
 
 #define V(ID, TT, SS, VEC, SHIFT, TUNE, MINW) \
   case ID: return go<TT, SS, VEC, SHIFT, TUNE, MINW>(in, out, n0, n1, n2, tau, cap, tpb, (hipStream_t)stream);
@@ -85,6 +137,14 @@ extern "C" int lt_experiment(int id, const void *in, void *out, int n0, int n1, 
     V(61, float, D3Q27, 1, 0, 2, 1)
     V(62, float, D3Q27, 2, 0, 2, 2)
     V(63, float, D3Q27, 2, 0, 0, 1)
+    V(46, float, D3Q19, 1, 0, 3, 1)
+    V(47, float, D3Q19, 1, 0, 1, 1)
+    M(70, float, D3Q19, 2, 2, 1)
+    M(71, float, D3Q19, 2, 3, 1)
+    M(72, float, D3Q19, 3, 2, 1)
+    M(73, float, D3Q19, 4, 2, 1)
+    M(74, float, D3Q19, 2, 2, 8)
+    M(75, float, D3Q19, 1, 2, 1)
     default: return -1;
   }
 }

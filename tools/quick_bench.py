@@ -66,7 +66,7 @@ def main():
                                   "mlups": round(n / ms / 1e3, 1), "GBps": round(n / ms / 1e3 * 2 * q * es / 1e3, 1)}), flush=True)
                 del a, b, plan
                 continue
-            variants = [(0, 0, -1, 0), (0, 0, 0, 0), (0, 0, 2, 0), (0, 0, 2, 8192), (1, 0, 0, 0), (1, 1, 0, 0),
+            variants = [(0, 0, -1, 0), (0, 0, 0, 0), (0, 0, 3, 0), (0, 0, 3, 8192), (1, 0, 0, 0), (1, 1, 0, 0),
                         (1, 2, 0, 0), (1, 0, 2, 0), (1, 2, 3, 0)]
             res = {}
             for r in range(rounds):
