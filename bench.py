@@ -28,6 +28,7 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")     # RCCL kernels beside the interior kernel
 
 import torch
 
@@ -48,6 +49,9 @@ def parse():
     ap.add_argument("--cpu-baseline-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="slab path: exchange without overlap")
+    ap.add_argument("--slab", action="store_true",
+                    help="use the z-slab driver (and an RCCL process group) even with one GPU: "
+                         "rehearsal of the N > 1 code path")
     return ap.parse_args()
 
 
@@ -114,11 +118,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    distributed = world > 1
+    distributed = world > 1 or args.slab
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     import lettuce_amd as lt
     ctx = lt.Context(device=device, dtype=torch.float32, use_native=True)

@@ -22,6 +22,7 @@ Schedule of one fused step (pull scheme, state = post-collision populations f*):
   4. both streams join before the next step.
 There is no collective on the step path; only observables use an all-reduce.
 """
+import os
 from timeit import default_timer as timer
 from typing import List, Optional
 
@@ -131,7 +132,12 @@ class SlabSimulation:
         self._send_up, self._send_down, self._recv_up, self._recv_down = new(), new(), new(), new()
         self._comm = (torch.cuda.Stream(device=self.context.device, priority=comm_priority)
                       if self.overlap else None)
-        self._host_transport = (slab.world_size > 1 and dist.get_backend(group) != "nccl")
+        # rehearsal switch: send to / receive from oneself through the process group even with a
+        # single rank, to exercise the point-to-point path on a one-GPU box
+        self._force_p2p = (os.environ.get("LT_SLAB_FORCE_P2P") == "1" and dist.is_available()
+                           and dist.is_initialized())
+        self._host_transport = ((slab.world_size > 1 or self._force_p2p)
+                                and dist.get_backend(group) != "nccl")
 
     # ---- views ---------------------------------------------------------------------------------
     def local_f(self) -> torch.Tensor:
@@ -175,7 +181,7 @@ class SlabSimulation:
         nzl, s = self.nzl, self.slab
         self._pack(buf, 1, -1, self._send_down)
         self._pack(buf, nzl, +1, self._send_up)
-        if s.world_size == 1:
+        if s.world_size == 1 and not self._force_p2p:
             recv_down, recv_up, reqs = self._send_down, self._send_up, []
         else:
             recv_down, recv_up = self._recv_down, self._recv_up
