@@ -201,6 +201,11 @@ int lt_plan_set_shift_policy(lt_plan *plan, int32_t policy);
  * and grid cap as lt_plan_set_tuning.  bench.py uses it to measure this device's copy ceiling. */
 int lt_probe_copy(void *dst_dev, const void *src_dev, int64_t n_bytes, int32_t cache_policy,
                   int32_t max_blocks, void *stream);
+/* hipGraph replay inside lt_run / lt_continue: the fused launches are captured 32 at a time into a
+ * graph and replayed.  mode 1 = always, 0 = never, -1 = automatic, which is "never" at present:
+ * on MI355X the eager launch loop was as fast or faster on small grids (3.5 vs 4.1 us per step at
+ * 128^2), see DESIGN.md. */
+int lt_plan_set_graph_mode(lt_plan *plan, int32_t mode);
 /* Tuning knobs.  cache_policy: -1 = automatic (nontemporal accesses when the populations exceed
  * the caches), else bit 0 = nontemporal loads, bit 1 = nontemporal stores (the one-node-per-
  * thread kernels exist for 0 and 3).  max_blocks > 0 caps the grid (grid-stride loop).

@@ -82,6 +82,7 @@ SYMBOLS = {
                                            ctypes.POINTER(_i64)]),
     "lt_plan_kernel_name": (ctypes.c_char_p, [_vp]),
     "lt_plan_set_shift_policy": (ctypes.c_int, [_vp, _i32]),
+    "lt_plan_set_graph_mode": (ctypes.c_int, [_vp, _i32]),
     "lt_plan_set_tuning": (ctypes.c_int, [_vp, _i32, _i32, _i32]),
     "lt_probe_copy": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
 }
@@ -365,6 +366,10 @@ class Plan:
 
     def set_shift_policy(self, policy: int):
         self._check(self.lib.lt_plan_set_shift_policy(self._handle, int(policy)))
+
+    def set_graph_mode(self, mode: int):
+        """-1 automatic (small grids), 0 never, 1 always replay the fused launches as a hipGraph"""
+        self._check(self.lib.lt_plan_set_graph_mode(self._handle, int(mode)))
 
     def set_tuning(self, cache_policy: int = -1, max_blocks: int = 0, wide: bool = False):
         self._check(self.lib.lt_plan_set_tuning(self._handle, int(cache_policy), int(max_blocks),

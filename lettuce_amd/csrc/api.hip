@@ -81,6 +81,13 @@ struct lt_plan {
   double *partial = nullptr;
   int masked = 0;
   char kernel_name[192];
+  // launch-bound grids: a captured hipGraph of kGraphChunk fused steps (ping-pong returns to the
+  // starting buffer), replayed on a plan-owned stream that is forked from / joined to the caller's
+  int graph_mode = -1;       // -1 automatic (small grids), 0 off, 1 always
+  hipStream_t gstream = nullptr;
+  hipEvent_t gev_in = nullptr, gev_out = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  struct { void *a, *b; double tau; int masked, tune, wide, shift, cap; } gkey = {};
 };
 
 namespace {
@@ -227,6 +234,63 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   return LT_OK;
 }
 
+constexpr int kGraphChunk = 32;            // fused steps per graph (even: ends in the start buffer)
+
+// Measured on MI355X (profiles/r01_small_grid_graph.jsonl): the eager C loop of lt_run already
+// runs at 3.5 us per step on 128^2 (dependent-kernel boundary ~1.5 us + kernel), and graph replay
+// was slower on three of four small grids (4.1 vs 3.5 us at 128^2; 4.6 vs 5.1 us at 256^2), so
+// "automatic" currently means eager; the graph path stays available with mode 1.
+bool graph_wanted(const lt_plan *p, long long fused) {
+  if (fused < 2 * kGraphChunk) return false;
+  return p->graph_mode == 1;
+}
+
+// Replays floor(fused / kGraphChunk) chunks of fused steps starting (and ending) in `cur`; returns
+// the number of steps done through the graph, or a negative status on failure.
+long long run_graph(lt_plan *p, void *cur, void *other, double tau, long long fused, void *stream) {
+  hipStream_t user = static_cast<hipStream_t>(stream);
+  if (!p->gstream) {
+    if (hipStreamCreateWithFlags(&p->gstream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&p->gev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->gev_out, hipEventDisableTiming) != hipSuccess)
+      return -fail(LT_ERR_HIP, "cannot create the graph stream/events");
+  }
+  const bool same = p->gexec && p->gkey.a == cur && p->gkey.b == other && p->gkey.tau == tau &&
+                    p->gkey.masked == p->masked && p->gkey.tune == p->tune &&
+                    p->gkey.wide == p->want_wide && p->gkey.shift == p->shift &&
+                    p->gkey.cap == p->grid_cap;
+  if (!same) {
+    if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(p->gstream, hipStreamCaptureModeThreadLocal) != hipSuccess)
+      return -fail(LT_ERR_HIP, "hipStreamBeginCapture failed");
+    void *c = cur, *o = other;
+    int rc = LT_OK;
+    for (int i = 0; i < kGraphChunk && rc == LT_OK; ++i) {
+      rc = step(p, lt::kFused, c, o, tau, 0, p->n2, p->gstream);
+      void *t = c; c = o; o = t;
+    }
+    const hipError_t e = hipStreamEndCapture(p->gstream, &graph);
+    if (rc != LT_OK) { if (graph) (void)hipGraphDestroy(graph); return -rc; }
+    if (e != hipSuccess || !graph) return -fail(LT_ERR_HIP, "hipStreamEndCapture failed");
+    const hipError_t ei = hipGraphInstantiate(&p->gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { p->gexec = nullptr; return -fail(LT_ERR_HIP, "hipGraphInstantiate failed"); }
+    p->gkey = {cur, other, tau, p->masked, p->tune, p->want_wide, p->shift, p->grid_cap};
+  }
+  const long long reps = fused / kGraphChunk;
+  if (hipEventRecord(p->gev_in, user) != hipSuccess ||
+      hipStreamWaitEvent(p->gstream, p->gev_in, 0) != hipSuccess)
+    return -fail(LT_ERR_HIP, "fork to the graph stream failed");
+  for (long long r = 0; r < reps; ++r)
+    if (hipGraphLaunch(p->gexec, p->gstream) != hipSuccess)
+      return -fail(LT_ERR_HIP, "hipGraphLaunch failed");
+  if (hipEventRecord(p->gev_out, p->gstream) != hipSuccess ||
+      hipStreamWaitEvent(user, p->gev_out, 0) != hipSuccess)
+    return -fail(LT_ERR_HIP, "join from the graph stream failed");
+  return reps * kGraphChunk;
+}
+
 int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, void *stream,
         int32_t *result_in_b) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
@@ -243,6 +307,11 @@ int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, 
     if (rc) return rc;
     void *t = cur; cur = other; other = t;
     fused = n - 1;
+  }
+  if (graph_wanted(p, fused)) {
+    const long long done = run_graph(p, cur, other, tau, fused, stream);
+    if (done < 0) return (int)-done;
+    fused -= done;                       // an even number of steps: still in `cur`
   }
   for (long long i = 0; i < fused; ++i) {
     rc = step(p, lt::kFused, cur, other, tau, 0, p->n2, stream);
@@ -350,6 +419,10 @@ int lt_plan_destroy(lt_plan *p) {
   if (p->nsm_bits) (void)hipFree(p->nsm_bits);
   if (p->bt) (void)hipFree(p->bt);
   if (p->partial) (void)hipFree(p->partial);
+  if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
+  if (p->gev_in) (void)hipEventDestroy(p->gev_in);
+  if (p->gev_out) (void)hipEventDestroy(p->gev_out);
+  if (p->gstream) (void)hipStreamDestroy(p->gstream);
   delete p;
   return LT_OK;
 }
@@ -501,6 +574,13 @@ int lt_plan_set_shift_policy(lt_plan *p, int32_t policy) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (policy < 0 || policy > 2) return fail(LT_ERR_INVALID, "shift policy %d", policy);
   p->shift = policy;
+  return LT_OK;
+}
+
+int lt_plan_set_graph_mode(lt_plan *p, int32_t mode) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (mode < -1 || mode > 1) return fail(LT_ERR_INVALID, "graph mode %d", mode);
+  p->graph_mode = mode;
   return LT_OK;
 }
 
