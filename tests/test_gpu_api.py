@@ -324,3 +324,69 @@ def test_non_native_mode_on_a_gpu_device():
     lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])(10)
     np.testing.assert_allclose(flow.f.cpu().numpy(), g["f10"], rtol=0, atol=1e-12)
     assert float(lt.IncompressibleKineticEnergy(flow)()) == pytest.approx(float(g["energy_pu"][1]), rel=1e-10)
+
+
+# ----------------------------------------------------------------------------- full BASELINE sizes
+def test_full_size_cfg4_obstacle_d3q27_kbc_properties():
+    """BASELINE configs[3] size (Obstacle D3Q27 256^3, KBC, fp32, inlet + ABB outlet + sphere
+    bounce-back): the fused masked kernel equals collide-then-stream at full size, the field stays
+    finite, and populations with e_x = 0 on the inlet plane are exactly the inlet equilibrium."""
+    c = gpu()
+    flow = lt.Obstacle(c, [256, 256, 256], 100, 0.1, domain_length_x=4, stencil=lt.D3Q27())
+    x, y, z = flow.grid
+    flow.mask = ((x - 1) ** 2 + (y - 2) ** 2 + (z - 2) ** 2) < 0.5 ** 2
+    flow.initialize()
+    sim = lt.Simulation(flow, lt.KBCCollision(), [])
+    plan, tau = sim._native.plan, flow.units.relaxation_parameter_lu
+    sim(3)                                             # 1 collide + 2 fused + 1 stream
+    f3 = flow.f.clone()
+    assert torch.isfinite(f3).all()
+    # same three steps as separate collide / stream passes
+    flow2 = lt.Obstacle(c, [256, 256, 256], 100, 0.1, domain_length_x=4, stencil=lt.D3Q27())
+    flow2.mask = flow.mask
+    flow2.initialize()
+    a, b = flow2.f, torch.empty_like(flow2.f)
+    for _ in range(3):
+        plan.collide(a, b, tau)
+        plan.stream(b, a)
+    torch.testing.assert_close(f3, a, rtol=0, atol=2e-6)
+    inlet = lt.EquilibriumBoundaryPU(c, None, velocity=[1.0, 0.0, 0.0])._feq(flow)
+    for q in (0, 3, 4, 5, 6, 7, 8, 9, 10):             # e_x = 0
+        assert torch.equal(f3[q, 0], inlet[q].expand(256, 256))
+    solid = flow.mask.to("cuda")
+    assert int(solid.sum()) > 100_000                   # the sphere is there
+
+
+def test_full_size_cfg5_slab_shear_fp64_conservation():
+    """BASELINE configs[4] per-GPU size (periodic shear, D3Q19 384 x 384 x 96, fp64): BGK on a
+    periodic box conserves mass and momentum to rounding over 20 steps."""
+    c = gpu("f64")
+    flow = lt.DoublyPeriodicShear3D(c, [384, 384, 96], 10000, 0.1)
+    sim = lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])
+    plan = sim._native.plan
+    m0 = float(plan.mass(flow.f).cpu())
+    j0 = flow.j().sum(dim=(1, 2, 3)).cpu()
+    sim(20)
+    assert float(plan.mass(flow.f).cpu()) == pytest.approx(m0, rel=1e-13)
+    j1 = flow.j().sum(dim=(1, 2, 3)).cpu()
+    assert torch.allclose(j1, j0, rtol=0, atol=1e-9 * 384 * 384 * 96 * 0.06)
+    assert torch.isfinite(flow.f).all()
+
+
+def test_full_size_cfg3_slab_equals_single_domain():
+    """BASELINE configs[2] per-GPU slab (512 x 512 x 64, fp32): the z-slab driver (slab-layout
+    kernels, boundary planes + packed ghost exchange on the second stream) gives the same
+    populations as the single-domain engine on the same periodic box."""
+    res = [512, 512, 64]
+    c = gpu()
+    slab = lt.ZSlab(res, rank=0, world_size=1)
+    fl_s = lt.TaylorGreenVortex(c, slab.extended_resolution, 1600, 0.1, lt.D3Q19(), slab=slab)
+    tau = fl_s.units.relaxation_parameter_lu
+    sim_s = lt.SlabSimulation(fl_s, lt.BGKCollision(tau), slab)
+    fl_p = lt.TaylorGreenVortex(c, res, 1600, 0.1, lt.D3Q19())
+    torch.testing.assert_close(sim_s.gather_f(), fl_p.f, rtol=0, atol=1e-6)
+    sim_p = lt.Simulation(fl_p, lt.BGKCollision(tau), [])
+    sim_s(6)
+    sim_p(6)
+    torch.testing.assert_close(sim_s.gather_f(), fl_p.f, rtol=0, atol=2e-6)
+    assert sim_s.kinetic_energy_pu() == pytest.approx(float(lt.IncompressibleKineticEnergy(fl_p)()), rel=1e-6)

@@ -295,3 +295,9 @@ def test_native_context_never_falls_back(monkeypatch):
     flow3.context.use_native = True
     with pytest.raises(lt.LettuceException, match="D3Q15"):
         lt.Simulation(flow3, lt.BGKCollision(0.8), [])
+
+
+def test_cli_benchmark_and_convergence_on_cpu(capsys):
+    from lettuce_amd.cli import main
+    assert main(["--no-cuda", "-p", "double", "benchmark", "-s", "3", "-r", "32", "-f", "taylor2D"]) == 0
+    assert "MLUPS" in capsys.readouterr().out
