@@ -127,6 +127,20 @@ def _stream_handle() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _on_device(method):
+    """Run a Plan method with the plan's GPU as the current device (kernel launches, the current
+    stream and allocations then all belong to it, whatever device the caller had selected)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        if torch.cuda.current_device() == self.device.index:
+            return method(self, *args, **kwargs)
+        with torch.cuda.device(self.device):
+            return method(self, *args, **kwargs)
+    return wrapper
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -172,6 +186,8 @@ class Plan:
         self.d = len(self.resolution)
         self.layout, self.ghost_planes = layout, ghost_planes
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self._keepalive = []
         desc = _PlanDesc()
         desc.abi_version = LT_ABI_VERSION
@@ -243,6 +259,7 @@ class Plan:
             pass
 
     # ------------------------------------------------------------------ masks
+    @_on_device
     def set_masks(self, no_collision_mask: Optional[torch.Tensor],
                   no_streaming_mask: Optional[torch.Tensor]):
         """uint8 ``[*res]`` / uint8 ``[q, *res]`` device tensors (either may be None)."""
@@ -262,6 +279,7 @@ class Plan:
         if nsm is not None:
             nsm.record_stream(torch.cuda.current_stream())
 
+    @_on_device
     def update_boundary(self, index: int, b: dict):
         d = _BoundaryDesc()
         self._fill_boundary(d, b)
@@ -269,30 +287,36 @@ class Plan:
                                                      _stream_handle()))
 
     # ------------------------------------------------------------------ operators
+    @_on_device
     def collide(self, f, out, tau):
         self._tensor_ok(f, self.f_shape); self._tensor_ok(out, self.f_shape)
         self._check(self.lib.lt_collide(self._handle, _ptr(f), _ptr(out), float(tau), _stream_handle()))
         return out
 
+    @_on_device
     def stream(self, f, out):
         self._tensor_ok(f, self.f_shape); self._tensor_ok(out, self.f_shape)
         self._check(self.lib.lt_stream(self._handle, _ptr(f), _ptr(out), _stream_handle()))
         return out
 
+    @_on_device
     def stream_collide(self, f, out, tau):
         self._tensor_ok(f, self.f_shape); self._tensor_ok(out, self.f_shape)
         self._check(self.lib.lt_stream_collide(self._handle, _ptr(f), _ptr(out), float(tau),
                                                _stream_handle()))
         return out
 
+    @_on_device
     def collide_planes(self, f, out, tau, begin, end):
         self._check(self.lib.lt_collide_planes(self._handle, _ptr(f), _ptr(out), float(tau),
                                                int(begin), int(end), _stream_handle()))
 
+    @_on_device
     def stream_planes(self, f, out, begin, end):
         self._check(self.lib.lt_stream_planes(self._handle, _ptr(f), _ptr(out), int(begin),
                                               int(end), _stream_handle()))
 
+    @_on_device
     def stream_collide_planes(self, f, out, tau, begin, end):
         self._check(self.lib.lt_stream_collide_planes(self._handle, _ptr(f), _ptr(out), float(tau),
                                                       int(begin), int(end), _stream_handle()))
@@ -303,18 +327,22 @@ class Plan:
         self._check(self.lib.lt_slab_crossing(self._handle, int(direction), qs, ctypes.byref(n)))
         return [int(qs[k]) for k in range(n.value)]
 
+    @_on_device
     def pack(self, f, plane, direction, buf):
         self._check(self.lib.lt_slab_pack(self._handle, _ptr(f), int(plane), int(direction), _ptr(buf),
                                           _stream_handle()))
 
+    @_on_device
     def unpack(self, f, plane, direction, buf):
         self._check(self.lib.lt_slab_unpack(self._handle, _ptr(f), int(plane), int(direction), _ptr(buf),
                                             _stream_handle()))
 
+    @_on_device
     def stream_collide_plane_pair(self, f, out, tau, first, second):
         self._check(self.lib.lt_stream_collide_plane_pair(self._handle, _ptr(f), _ptr(out), float(tau),
                                                           int(first), int(second), _stream_handle()))
 
+    @_on_device
     def run(self, a, b, tau, n_steps, from_fstar=False):
         """n whole steps; returns (result, other): ``result`` holds the new post-streaming
         populations, ``other`` the post-collision populations of the last step."""
@@ -325,6 +353,7 @@ class Plan:
                        ctypes.byref(which)))
         return (b, a) if which.value else (a, b)
 
+    @_on_device
     def macroscopic(self, f, want_rho=True, want_u=True):
         self._tensor_ok(f, self.f_shape)
         grid = self.f_shape[1:]
@@ -333,6 +362,7 @@ class Plan:
         self._check(self.lib.lt_macroscopic(self._handle, _ptr(f), _ptr(rho), _ptr(u), _stream_handle()))
         return rho, u
 
+    @_on_device
     def equilibrium(self, rho, u):
         grid = self.f_shape[1:]
         rho = rho.reshape(grid).contiguous()
@@ -341,6 +371,7 @@ class Plan:
         self._check(self.lib.lt_equilibrium(self._handle, _ptr(rho), _ptr(u), _ptr(feq), _stream_handle()))
         return feq
 
+    @_on_device
     def kinetic_energy_lu(self, f):
         """0-d float64 device tensor: sum over nodes of 0.5 u.u (lattice units)."""
         self._tensor_ok(f, self.f_shape)
@@ -348,6 +379,7 @@ class Plan:
         self._check(self.lib.lt_kinetic_energy(self._handle, _ptr(f), _ptr(out), _stream_handle()))
         return out
 
+    @_on_device
     def mass(self, f):
         self._tensor_ok(f, self.f_shape)
         out = torch.empty((), dtype=torch.float64, device=f.device)
