@@ -189,6 +189,10 @@ int lt_kinetic_energy(lt_plan *plan, const void *f_dev, double *out_dev, void *s
 /* *out_dev = sum over nodes and populations of f (total mass, fp64 accumulation). */
 int lt_mass(lt_plan *plan, const void *f_dev, double *out_dev, void *stream);
 
+/* *out_dev = max over nodes of |u| in lattice units (MaximumVelocity observable,
+ * lettuce/ext/_reporter/observable_reporter.py:27-31; the pu scaling stays on the host). */
+int lt_max_velocity(lt_plan *plan, const void *f_dev, double *out_dev, void *stream);
+
 /* Introspection for tests and benchmarks. */
 int lt_plan_kernel_info(lt_plan *plan, int32_t *vec_width, int32_t *threads_per_block,
                         int64_t *blocks_per_launch);

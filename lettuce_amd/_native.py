@@ -78,6 +78,7 @@ SYMBOLS = {
     "lt_equilibrium": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "lt_kinetic_energy": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "lt_mass": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "lt_max_velocity": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "lt_plan_kernel_info": (ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i32),
                                            ctypes.POINTER(_i64)]),
     "lt_plan_kernel_name": (ctypes.c_char_p, [_vp]),
@@ -384,6 +385,14 @@ class Plan:
         self._tensor_ok(f, self.f_shape)
         out = torch.empty((), dtype=torch.float64, device=f.device)
         self._check(self.lib.lt_mass(self._handle, _ptr(f), _ptr(out), _stream_handle()))
+        return out
+
+    @_on_device
+    def max_velocity_lu(self, f):
+        """0-d float64 device tensor: max over nodes of |u| (lattice units)"""
+        self._tensor_ok(f, self.f_shape)
+        out = torch.empty((), dtype=torch.float64, device=f.device)
+        self._check(self.lib.lt_max_velocity(self._handle, _ptr(f), _ptr(out), _stream_handle()))
         return out
 
     # ------------------------------------------------------------------ introspection

@@ -508,6 +508,10 @@ int lt_mass(lt_plan *p, const void *f, double *out, void *s) {
   if (!out) return fail(LT_ERR_INVALID, "null output");
   return aux(p, 3, f, nullptr, nullptr, out, s);
 }
+int lt_max_velocity(lt_plan *p, const void *f, double *out, void *s) {
+  if (!out) return fail(LT_ERR_INVALID, "null output");
+  return aux(p, 4, f, nullptr, nullptr, out, s);
+}
 
 int lt_plan_kernel_info(lt_plan *p, int32_t *vec, int32_t *tpb, int64_t *blocks) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");

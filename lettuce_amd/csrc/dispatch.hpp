@@ -26,7 +26,7 @@ struct StepArgs {
 };
 
 struct AuxArgs {
-  int what;              // 0 macroscopic, 1 equilibrium, 2 kinetic energy, 3 mass
+  int what;              // 0 macroscopic, 1 equilibrium, 2 kinetic energy, 3 mass, 4 max |u|
   int layout;
   const void *f;         // populations (what 0, 2, 3) / feq output (what 1; cast away const)
   void *rho;             // what 0: out, what 1: in

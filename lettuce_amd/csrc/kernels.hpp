@@ -635,23 +635,29 @@ __global__ void __launch_bounds__(kThreads) equilibrium_kernel(const T *__restri
   });
 }
 
-// wavefront (64-lane) + workgroup reduction of a double; result valid in thread 0
+// wavefront (64-lane) + workgroup reduction of a double (sum, or max when MAX); result valid in
+// thread 0
+template <bool MAX = false>
 __device__ __forceinline__ double block_sum(double v) {
   __shared__ double part[kThreads / 64];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(v, off);
+    v = MAX ? (o > v ? o : v) : v + o;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) part[wave] = v;
   __syncthreads();
   double s = 0.0;
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int w = 0; w < kThreads / 64; ++w) s += part[w];
+    for (int w = 0; w < kThreads / 64; ++w) s = MAX ? (part[w] > s ? part[w] : s) : s + part[w];
   }
   return s;
 }
 
-// per-block partial sums of 0.5*u.u (MODE 0) or of sum_q f (MODE 1) over the planes
+// per-block partial sums of 0.5*u.u (MODE 0) or of sum_q f (MODE 1), or per-block maximum of |u|
+// (MODE 2), over the planes
 // [p_begin, p_begin + planes) of a2; fixed grid -> fixed summation order.
 template <typename T, class S, int LAYOUT, int MODE>
 __global__ void __launch_bounds__(kThreads) reduce_kernel(const T *__restrict__ f, long long N,
@@ -670,19 +676,24 @@ __global__ void __launch_bounds__(kThreads) reduce_kernel(const T *__restrict__ 
     if constexpr (MODE == 0) {
       const T ux = j[0] / rho, uy = j[1] / rho, uz = j[2] / rho;
       acc += (double)(T(0.5) * (ux * ux + uy * uy + uz * uz));
-    } else {
+    } else if constexpr (MODE == 1) {
       acc += (double)rho;
+    } else {
+      const T ux = j[0] / rho, uy = j[1] / rho, uz = j[2] / rho;
+      const double m = (double)sqrt(ux * ux + uy * uy + uz * uz);
+      acc = m > acc ? m : acc;
     }
   }
-  const double s = block_sum(acc);
+  const double s = block_sum<MODE == 2>(acc);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+template <bool MAX>
 static __global__ void __launch_bounds__(kThreads) finish_sum_kernel(const double *__restrict__ partial,
                                                               int n, double *__restrict__ out) {
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += kThreads) acc += partial[i];
-  const double s = block_sum(acc);
+  for (int i = threadIdx.x; i < n; i += kThreads) acc = MAX ? (partial[i] > acc ? partial[i] : acc) : acc + partial[i];
+  const double s = block_sum<MAX>(acc);
   if (threadIdx.x == 0) *out = s;
 }
 

@@ -30,7 +30,13 @@ class Observable(ABC):
 
 
 class MaximumVelocity(Observable):
+    """max |u| in physical units (observable_reporter.py:27-31); a device max-reduction on a
+    native context."""
+
     def __call__(self, f: Optional[torch.Tensor] = None):
+        plan = self.flow._engine_plan(self.flow.f)
+        if plan is not None:
+            return self.flow.units.convert_velocity_to_pu(plan.max_velocity_lu(self.flow.f))
         return torch.norm(self.flow.u_pu, dim=0).max()
 
 

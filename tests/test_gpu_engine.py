@@ -207,6 +207,8 @@ def test_whole_field_operators(lat, dt):
     assert_close(out.cpu().numpy(), g["bgk"], dt)
     ke = float(plan.kinetic_energy_lu(f).cpu())
     assert ke == pytest.approx(float(g["energy"].astype(np.float64).sum()), rel=1e-12 if dt == "f64" else 2e-6)
+    umax = float(plan.max_velocity_lu(f).cpu())
+    assert umax == pytest.approx(float(np.sqrt((g["u"].astype(np.float64) ** 2).sum(axis=0)).max()), rel=1e-12 if dt == "f64" else 1e-6)
     mass = float(plan.mass(f).cpu())
     assert mass == pytest.approx(float(g["f"].astype(np.float64).sum()), rel=1e-12 if dt == "f64" else 1e-6)
     bb = plan_for(lat, TORCH_DT[dt], "none", g["f"].shape[1:], [{"kind": "bounce_back"}])
