@@ -18,6 +18,8 @@ from typing import Optional, Sequence
 
 import torch
 
+from ._errors import LettuceException
+
 __all__ = ["NativeEngineError", "load_library", "library_path", "Plan", "STENCIL_IDS",
            "COLLISION_IDS", "BOUNDARY_KINDS"]
 
@@ -32,10 +34,10 @@ BOUNDARY_KINDS = {"bounce_back": 1, "equilibrium": 2, "abb_outlet": 3}
 LAYOUT_REFERENCE, LAYOUT_SLAB = 0, 1
 
 
-class NativeEngineError(Exception):
-    """Raised for every failure of the HIP engine (library missing, unsupported
-    configuration, HIP error).  ``lettuce_amd.LettuceException`` derives from the same base
-    the reference uses (lettuce/util/utility.py:21-22); this subclass is re-exported there."""
+class NativeEngineError(LettuceException):
+    """Raised for every failure of the HIP engine (library missing, unsupported configuration,
+    HIP error).  A ``LettuceException`` (lettuce/util/utility.py:21-22), so reference-style
+    ``except LettuceException`` handlers see it; the interpreter is never aborted."""
 
 
 class _BoundaryDesc(ctypes.Structure):

@@ -208,6 +208,21 @@ class Obstacle(ExtFlow):
         return torch.eye(self.stencil.d)[i]
 
 
+def _deprecated_obstacle(name):
+    def factory(context, resolution, reynolds_number, mach_number, stencil, char_length_lu):
+        warnings.warn(f"{name} is deprecated. Use Obstacle instead", DeprecationWarning)
+        nx = resolution[0] if isinstance(resolution, list) else resolution
+        return Obstacle(context=context, resolution=resolution, reynolds_number=reynolds_number,
+                        mach_number=mach_number, domain_length_x=nx / char_length_lu, stencil=stencil)
+    factory.__name__ = name
+    return factory
+
+
+# present in the reference's module but not exported (obstacle.py:13,128-151)
+Obstacle2D = _deprecated_obstacle("Obstacle2D")
+Obstacle3D = _deprecated_obstacle("Obstacle3D")
+
+
 def _shear_axes(flow):
     return torch.meshgrid(*_periodic_axes(flow.resolution, 1, flow.context,
                                           getattr(flow, "slab", None)), indexing="ij")

@@ -9,30 +9,11 @@ import inspect
 
 import torch
 
-from ._native import NativeEngineError as _NativeEngineError
+from ._errors import LettuceException, LettuceWarning, InefficientCodeWarning, ExperimentalWarning
+from ._native import NativeEngineError
 
 __all__ = ["LettuceException", "LettuceWarning", "InefficientCodeWarning", "ExperimentalWarning",
            "NativeEngineError", "torch_gradient", "append_axes", "get_subclasses"]
-
-
-class LettuceException(Exception):
-    pass
-
-
-class NativeEngineError(_NativeEngineError, LettuceException):
-    """HIP engine failure surfaced as a LettuceException."""
-
-
-class LettuceWarning(UserWarning):
-    pass
-
-
-class InefficientCodeWarning(LettuceWarning):
-    pass
-
-
-class ExperimentalWarning(LettuceWarning):
-    pass
 
 
 def get_subclasses(cls, module):
