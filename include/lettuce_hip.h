@@ -201,8 +201,9 @@ const char *lt_plan_kernel_name(lt_plan *plan);
 /* 16-byte variant only: 0 = aligned vector load + one neighbour element, 1 = unaligned vector
  * load, 2 = aligned vector load + cross-lane shift. */
 int lt_plan_set_shift_policy(lt_plan *plan, int32_t policy);
-/* Diagnostic: dst[0:n_bytes] = src[0:n_bytes] with 16-byte accesses, the same cache-policy bits
- * and grid cap as lt_plan_set_tuning.  bench.py uses it to measure this device's copy ceiling. */
+/* Diagnostic: dst[0:n_bytes] = src[0:n_bytes] with 16-byte accesses and the cache-policy bits of
+ * lt_plan_set_tuning; max_blocks > 0 caps its grid (grid-stride loop).  bench.py uses it to
+ * measure this device's copy ceiling. */
 int lt_probe_copy(void *dst_dev, const void *src_dev, int64_t n_bytes, int32_t cache_policy,
                   int32_t max_blocks, void *stream);
 /* hipGraph replay inside lt_run / lt_continue: the fused launches are captured 32 at a time into a
@@ -212,10 +213,10 @@ int lt_probe_copy(void *dst_dev, const void *src_dev, int64_t n_bytes, int32_t c
 int lt_plan_set_graph_mode(lt_plan *plan, int32_t mode);
 /* Tuning knobs.  cache_policy: -1 = automatic (nontemporal accesses when the populations exceed
  * the caches), else bit 0 = nontemporal loads, bit 1 = nontemporal stores (the one-node-per-
- * thread kernels exist for 0 and 3).  max_blocks > 0 caps the grid (grid-stride loop).
+ * thread kernels exist for 0 and 3).
  * wide != 0 switches the hot kernel (fused, BGK, no masks) to its 16-byte-per-lane A/B variant,
  * whose shift handling lt_plan_set_shift_policy selects. */
-int lt_plan_set_tuning(lt_plan *plan, int32_t cache_policy, int32_t max_blocks, int32_t wide);
+int lt_plan_set_tuning(lt_plan *plan, int32_t cache_policy, int32_t wide);
 
 #ifdef __cplusplus
 }

@@ -86,7 +86,7 @@ SYMBOLS = {
     "lt_plan_kernel_name": (ctypes.c_char_p, [_vp]),
     "lt_plan_set_shift_policy": (ctypes.c_int, [_vp, _i32]),
     "lt_plan_set_graph_mode": (ctypes.c_int, [_vp, _i32]),
-    "lt_plan_set_tuning": (ctypes.c_int, [_vp, _i32, _i32, _i32]),
+    "lt_plan_set_tuning": (ctypes.c_int, [_vp, _i32, _i32]),
     "lt_probe_copy": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
 }
 
@@ -414,6 +414,5 @@ class Plan:
         """-1 automatic (small grids), 0 never, 1 always replay the fused launches as a hipGraph"""
         self._check(self.lib.lt_plan_set_graph_mode(self._handle, int(mode)))
 
-    def set_tuning(self, cache_policy: int = -1, max_blocks: int = 0, wide: bool = False):
-        self._check(self.lib.lt_plan_set_tuning(self._handle, int(cache_policy), int(max_blocks),
-                                                int(bool(wide))))
+    def set_tuning(self, cache_policy: int = -1, wide: bool = False):
+        self._check(self.lib.lt_plan_set_tuning(self._handle, int(cache_policy), int(bool(wide))))

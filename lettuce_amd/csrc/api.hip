@@ -72,7 +72,6 @@ struct lt_plan {
   int wide_ok;               // n0 divisible by the 16-byte vector width
   int shift;
   int tune = -1;             // cache policy: -1 = automatic
-  int grid_cap = 0;
   int want_wide = 0;         // 16-byte accesses for the hot kernel (A/B experiments)
   // engine-owned device scratch
   unsigned char *node = nullptr;
@@ -87,7 +86,7 @@ struct lt_plan {
   hipStream_t gstream = nullptr;
   hipEvent_t gev_in = nullptr, gev_out = nullptr;
   hipGraphExec_t gexec = nullptr;
-  struct { void *a, *b; double tau; int masked, tune, wide, shift, cap; } gkey = {};
+  struct { void *a, *b; double tau; int masked, tune, wide, shift; } gkey = {};
 };
 
 namespace {
@@ -224,7 +223,6 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.wide = (p->want_wide && hot && p->wide_ok && aligned) ? 1 : 0;
   a.shift = a.wide ? p->shift : 0;
   a.tune = resolve_tune(p, a.wide);
-  a.grid_cap = p->grid_cap;
   a.stream = static_cast<hipStream_t>(stream);
   const int r = p->unit.step(a);
   if (r == lt::kNoKernel)
@@ -257,8 +255,7 @@ long long run_graph(lt_plan *p, void *cur, void *other, double tau, long long fu
   }
   const bool same = p->gexec && p->gkey.a == cur && p->gkey.b == other && p->gkey.tau == tau &&
                     p->gkey.masked == p->masked && p->gkey.tune == p->tune &&
-                    p->gkey.wide == p->want_wide && p->gkey.shift == p->shift &&
-                    p->gkey.cap == p->grid_cap;
+                    p->gkey.wide == p->want_wide && p->gkey.shift == p->shift;
   if (!same) {
     if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
     hipGraph_t graph = nullptr;
@@ -276,7 +273,7 @@ long long run_graph(lt_plan *p, void *cur, void *other, double tau, long long fu
     const hipError_t ei = hipGraphInstantiate(&p->gexec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) { p->gexec = nullptr; return -fail(LT_ERR_HIP, "hipGraphInstantiate failed"); }
-    p->gkey = {cur, other, tau, p->masked, p->tune, p->want_wide, p->shift, p->grid_cap};
+    p->gkey = {cur, other, tau, p->masked, p->tune, p->want_wide, p->shift};
   }
   const long long reps = fused / kGraphChunk;
   if (hipEventRecord(p->gev_in, user) != hipSuccess ||
@@ -588,12 +585,10 @@ int lt_plan_set_graph_mode(lt_plan *p, int32_t mode) {
   return LT_OK;
 }
 
-int lt_plan_set_tuning(lt_plan *p, int32_t cache_policy, int32_t max_blocks, int32_t wide) {
+int lt_plan_set_tuning(lt_plan *p, int32_t cache_policy, int32_t wide) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (cache_policy < -1 || cache_policy > 3) return fail(LT_ERR_INVALID, "cache policy %d", cache_policy);
-  if (max_blocks < 0) return fail(LT_ERR_INVALID, "max_blocks %d", max_blocks);
   p->tune = cache_policy;
-  p->grid_cap = max_blocks;
   p->want_wide = wide ? 1 : 0;
   return LT_OK;
 }

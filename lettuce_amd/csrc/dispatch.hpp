@@ -21,7 +21,6 @@ struct StepArgs {
   const void *bt;        // BoundaryTable<T>* (device)
   int nb;
   int layout, coll, mode, masked, wide, shift, tune;
-  int grid_cap;          // > 0: launch at most this many blocks (grid-stride loop)
   hipStream_t stream;
 };
 

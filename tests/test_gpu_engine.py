@@ -236,21 +236,17 @@ def test_fused_equals_collide_then_stream_and_ab_variants_agree():
         tol = 2e-7 if f.dtype == torch.float32 else 4e-16
         torch.testing.assert_close(b, a, rtol=0, atol=tol)
         for cache in (0, 3):
-            plan.set_tuning(cache, 0, False)
+            plan.set_tuning(cache, False)
             c = torch.empty_like(f)
             plan.stream_collide(f, c, tau)
             assert torch.equal(c, b)
         for shift, cache in ((0, 0), (1, 0), (2, 0), (0, 2), (2, 3)):
-            plan.set_tuning(cache, 0, True)
+            plan.set_tuning(cache, True)
             plan.set_shift_policy(shift)
             assert plan.kernel_info()["vec"] == 16 // f.element_size()
             c = torch.empty_like(f)
             plan.stream_collide(f, c, tau)
             torch.testing.assert_close(c, b, rtol=0, atol=tol)
-        plan.set_tuning(-1, 512, False)           # capped grid -> grid-stride loop
-        c = torch.empty_like(f)
-        plan.stream_collide(f, c, tau)
-        assert torch.equal(c, b)
 
 
 def test_energy_decay_series_fp64():

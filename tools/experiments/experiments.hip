@@ -23,7 +23,7 @@ static int go(const void *in, void *out, int n0, int n1, int n2, double tau, int
   p.node = nullptr; p.nsm_bits = nullptr; p.bt = nullptr; p.nb = 0;
   if (tpb <= 0) tpb = 256;
   unsigned grid = (p.nvec_total + tpb - 1) / tpb;
-  if (cap > 0 && grid > (unsigned)cap) grid = cap;
+  (void)cap;   // the kernel body no longer has a grid-stride loop
   if (SHIFT == 3 && n0 != 64 * VEC) return -2;
   hipLaunchKernelGGL((exp_kernel<T, S, VEC, SHIFT, TUNE, MINW>), dim3(grid), dim3(tpb), 0, st, p);
   return (int)hipGetLastError();
@@ -80,6 +80,39 @@ static int go_multi(const void *in, void *out, int n0, int n1, int n2, double ta
 }
 #define M(ID, TT, SS, NODES, TUNE, MINW) \
   case ID: return go_multi<TT, SS, NODES, TUNE, MINW>(in, out, n0, n1, n2, tau, tpb, (hipStream_t)stream);
+
+// KBC variants (periodic): LEAN on/off x launch-bounds min waves
+template <typename T, class S, bool LEAN, int MINW>
+__global__ void __launch_bounds__(256, MINW) kbc_kernel(const KParams<T> p) {
+  const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= p.nvec_total) return;
+  const unsigned rowid = v / (unsigned)p.nv0;
+  const int c0 = (int)(v - rowid * (unsigned)p.nv0);
+  const int r2 = (int)(rowid / (unsigned)p.n1);
+  const int c1 = (int)(rowid - (unsigned)r2 * (unsigned)p.n1);
+  const Coord c = make_coord(p, c0, c1, r2);
+  const unsigned own = (unsigned)(r2 * p.n1 + c1) * (unsigned)p.n0 + (unsigned)c0;
+  T f[S::Q][1];
+  gather<T, S, 0, true, 1, 0, true>(p, c, f);
+  collide_kbc<T, S, 0, 1, 0, LEAN>(f, p.beta, p.inv_beta);
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    vstore<T, 1, true>(p.out + (long long)q * p.N + own, f[q]);
+  });
+}
+template <typename T, class S, bool LEAN, int MINW>
+static int go_kbc(const void *in, void *out, int n0, int n1, int n2, double tau, hipStream_t st) {
+  KParams<T> p;
+  p.in = (const T *)in; p.out = (T *)out;
+  p.n0 = n0; p.n1 = n1; p.n2 = n2; p.nv0 = n0; p.p_begin = 0; p.p_stride = 1; p.wrap2 = 1;
+  p.N = (long long)n0 * n1 * n2; p.nvec_total = (unsigned)p.N;
+  p.tau_inv = (T)(1.0 / tau); const double beta = 1. / (2 * tau); p.beta = (T)beta; p.inv_beta = (T)(1. / beta);
+  p.node = nullptr; p.nsm_bits = nullptr; p.bt = nullptr; p.nb = 0;
+  hipLaunchKernelGGL((kbc_kernel<T, S, LEAN, MINW>), dim3((p.nvec_total + 255) / 256), dim3(256), 0, st, p);
+  return (int)hipGetLastError();
+}
+#define K(ID, TT, SS, LEAN, MINW) \
+  case ID: return go_kbc<TT, SS, LEAN, MINW>(in, out, n0, n1, n2, tau, (hipStream_t)stream);
 
 #define V(ID, TT, SS, VEC, SHIFT, TUNE, MINW) \
   case ID: return go<TT, SS, VEC, SHIFT, TUNE, MINW>(in, out, n0, n1, n2, tau, cap, tpb, (hipStream_t)stream);
@@ -145,6 +178,15 @@ extern "C" int lt_experiment(int id, const void *in, void *out, int n0, int n1, 
     M(73, float, D3Q19, 4, 2, 1)
     M(74, float, D3Q19, 2, 2, 8)
     M(75, float, D3Q19, 1, 2, 1)
+    K(80, float, D3Q27, false, 1)
+    K(81, float, D3Q27, false, 4)
+    K(82, float, D3Q27, true, 1)
+    K(83, float, D3Q27, true, 6)
+    K(84, double, D3Q27, false, 1)
+    K(85, double, D3Q27, true, 1)
+    K(86, double, D3Q27, false, 2)
+    K(87, float, D2Q9, false, 1)
+    K(88, float, D2Q9, true, 1)
     default: return -1;
   }
 }

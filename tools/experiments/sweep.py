@@ -21,7 +21,8 @@ def run(vid, a, b, n, cap, iters, tpb=256):
 
 def main():
     groups = {"d3q19_f32": (19, torch.float32, [41, 46]), "d3q19_f64": (19, torch.float64, [20, 25, 26, 50, 51]),
-              "d3q27_f32": (27, torch.float32, [30, 35, 36, 61, 62, 63])}
+              "d3q27_f32": (27, torch.float32, [30, 35, 36, 61, 62, 63]),
+              "kbc27_f32": (27, torch.float32, [80, 81, 82, 83]), "kbc27_f64": (27, torch.float64, [84, 85, 86])}
     sel = sys.argv[1:] or list(groups)
     rounds = int(os.environ.get("ROUNDS", 3)); caps = [int(c) for c in os.environ.get("CAPS", "0").split(",")]
     tpbs = [int(c) for c in os.environ.get("TPBS", "256").split(",")]

@@ -71,7 +71,7 @@ def main():
             res = {}
             for r in range(rounds):
                 for wide, shift, tune, cap in variants:
-                    plan.set_shift_policy(shift); plan.set_tuning(tune, cap, bool(wide))
+                    plan.set_shift_policy(shift); plan.set_tuning(tune, bool(wide))
                     res.setdefault((wide, shift, tune, cap), []).append(time_fused(plan, a, b, 0.6, 20))
             for (wide, shift, tune, cap), v in res.items():
                 ms = med(v); mlups = n / ms / 1e3
