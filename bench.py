@@ -29,6 +29,10 @@ import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
 os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")     # RCCL kernels beside the interior kernel
+# stdout carries exactly one JSON line: RCCL's NCCL_DEBUG=VERSION banner (exported on the GPU boxes)
+# goes to stdout, so keep RCCL to warnings and send those to stderr
+os.environ["NCCL_DEBUG"] = "WARN"
+os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
 
 import torch
 
