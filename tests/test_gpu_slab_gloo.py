@@ -36,12 +36,14 @@ def _worker(rank, world, port, res, steps, dtype_name, overlap, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [True, False], ids=["overlap", "serial"])
-def test_two_ranks_one_gpu(tmp_path, overlap):
+@pytest.mark.parametrize("world,overlap", [(2, True), (2, False), (4, True)],
+                         ids=["2ranks-overlap", "2ranks-serial", "4ranks-overlap"])
+def test_ranks_sharing_one_gpu(tmp_path, world, overlap):
+    """2 ranks: both neighbours are the same peer; 4 ranks: distinct lower / upper neighbours."""
     from oracle import lettuce_oracle as orc
     res, steps = [32, 16, 16], 6
-    port = 29700 + (os.getpid() % 1000) + int(overlap)
-    mp.spawn(_worker, args=(2, port, res, steps, "float64", overlap, str(tmp_path)), nprocs=2, join=True)
+    port = 29700 + (os.getpid() % 1000) + int(overlap) + 10 * world
+    mp.spawn(_worker, args=(world, port, res, steps, "float64", overlap, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "out.npz")
     ref = orc.taylor_green(res, 400, 0.1, "D3Q19", torch.float64)
     ref.step(steps)
