@@ -107,7 +107,8 @@ int lt_plan_destroy(lt_plan *plan);
  * lettuce/_simulation.py:73-82) and Simulation.no_streaming_mask (uint8 [q, *res], 0/1,
  * :83-86; may be NULL) into the plan's node-descriptor byte (+ a sparse per-node bit set for
  * the streaming mask).  Both NULL removes the masks.  Required before stepping a plan that
- * has boundaries. */
+ * has boundaries.  The masks are indexed like the populations of the plan's layout: in the slab
+ * layout uint8 [nz + 2][ny][nx] and [q][nz + 2][ny][nx] (ghost-plane entries are ignored). */
 int lt_plan_set_masks(lt_plan *plan, const uint8_t *no_collision_mask_dev,
                       const uint8_t *no_streaming_mask_dev, void *stream);
 

@@ -269,12 +269,14 @@ class Plan:
         ncm = nsm = None
         if no_collision_mask is not None:
             ncm = no_collision_mask.to(device=self.device, dtype=torch.uint8).contiguous()
-            if list(ncm.shape) != self.resolution:
-                raise NativeEngineError(f"no_collision_mask shape {list(ncm.shape)}")
+            if list(ncm.shape) != self.f_shape[1:]:
+                raise NativeEngineError(f"no_collision_mask shape {list(ncm.shape)}, expected "
+                                        f"{self.f_shape[1:]}")
         if no_streaming_mask is not None:
             nsm = no_streaming_mask.to(device=self.device, dtype=torch.uint8).contiguous()
-            if list(nsm.shape) != [self.q] + self.resolution:
-                raise NativeEngineError(f"no_streaming_mask shape {list(nsm.shape)}")
+            if list(nsm.shape) != self.f_shape:
+                raise NativeEngineError(f"no_streaming_mask shape {list(nsm.shape)}, expected "
+                                        f"{self.f_shape}")
         self._check(self.lib.lt_plan_set_masks(self._handle, _ptr(ncm), _ptr(nsm), _stream_handle()))
         # the compile kernel reads them asynchronously on the current stream
         if ncm is not None:

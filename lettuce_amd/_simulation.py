@@ -49,6 +49,26 @@ class Reporter(ABC):
         ...
 
 
+def build_masks(flow, boundaries, context):
+    """no_collision_mask (uint8 [*res], value = boundary index, later boundaries overwrite
+    earlier ones) and no_streaming_mask (uint8 [q, *res], OR of all) for ``boundaries`` =
+    ``[None] + sorted(flow.boundaries, key=str)``; (None, None) without boundaries
+    (lettuce/_simulation.py:63-86)."""
+    if len(boundaries) <= 1:
+        return None, None
+    grid = [n for n in flow.f.shape[1:]]
+    ncm = context.zero_tensor(flow.resolution, dtype=torch.uint8)
+    nsm = context.zero_tensor([flow.stencil.q, *flow.resolution], dtype=torch.uint8)
+    for index, boundary in enumerate(boundaries[1:], start=1):
+        mask = boundary.make_no_collision_mask(grid, context=context)
+        if mask is not None:
+            ncm[mask] = index            # last writer wins
+        mask = boundary.make_no_streaming_mask([flow.stencil.q] + grid, context=context)
+        if mask is not None:
+            nsm |= mask
+    return ncm, nsm
+
+
 def _version(t: Optional[torch.Tensor]):
     return None if t is None else (id(t), t.data_ptr(), t._version, tuple(t.shape))
 
@@ -208,20 +228,8 @@ class Simulation:
         # sorts by class path, as in the reference (lettuce/_simulation.py:57-58)
         self.boundaries = [None] + sorted(flow.boundaries, key=lambda b: str(b))
 
-        self.no_collision_mask = None
-        self.no_streaming_mask = None
-        if len(self.boundaries) > 1:
-            grid = [n for n in self.flow.f.shape[1:]]
-            self.no_collision_mask = self.context.zero_tensor(flow.resolution, dtype=torch.uint8)
-            self.no_streaming_mask = self.context.zero_tensor([flow.stencil.q, *flow.resolution],
-                                                              dtype=torch.uint8)
-            for index, boundary in enumerate(self.boundaries[1:], start=1):
-                ncm = boundary.make_no_collision_mask(grid, context=self.context)
-                if ncm is not None:
-                    self.no_collision_mask[ncm] = index            # last writer wins
-                nsm = boundary.make_no_streaming_mask([flow.stencil.q] + grid, context=self.context)
-                if nsm is not None:
-                    self.no_streaming_mask |= nsm
+        self.no_collision_mask, self.no_streaming_mask = build_masks(flow, self.boundaries,
+                                                                     self.context)
 
         def collide_and_stream(*_, **__):
             self._collide()

@@ -88,17 +88,16 @@ def _crossing_sets(stencil):
 class SlabSimulation:
     """Time-step driver of one rank's slab.
 
-    ``flow`` is a periodic flow built on ``slab.extended_resolution`` with ``slab=slab`` (so
-    that its initial condition equals the global one on this rank's planes); ``collision`` is a
-    BGK / KBC / NoCollision object.  ``engine`` defaults to the HIP engine; tests inject a
+    ``flow`` is built on ``slab.extended_resolution`` with ``slab=slab`` (so that its initial
+    condition and its boundary masks equal the global ones on this rank's planes); ``collision``
+    is a BGK / KBC / NoCollision object.  Boundaries may be bounce-back, uniform equilibrium and
+    an anti-bounce-back outlet along x or y (not along the decomposed z axis).  ``engine`` defaults to the HIP engine; tests inject a
     CPU stand-in with the same three ``*_planes`` methods to exercise the decomposition and the
     exchange with the gloo backend.
     """
 
     def __init__(self, flow, collision, slab: ZSlab, reporter=None, engine=None, group=None,
                  overlap: bool = True, comm_priority: int = -1):
-        if flow.boundaries:
-            raise LettuceException("the slab driver handles periodic flows (no boundaries)")
         if list(flow.resolution) != slab.extended_resolution:
             raise LettuceException(f"flow resolution {flow.resolution} != extended slab "
                                    f"{slab.extended_resolution}")
@@ -114,11 +113,33 @@ class SlabSimulation:
         self.up, self.down = _crossing_sets(flow.stencil)
         desc = collision.native_generator()
         self._tau = desc.tau
+        # boundaries: same ordering and masks as Simulation (built on the extended slab, then cut
+        # to this rank's planes + one ghost plane per side and laid out z-slowest)
+        from ._simulation import build_masks
+        self.boundaries = [None] + sorted(flow.boundaries, key=lambda b: str(b))
+        ncm, nsm = build_masks(flow, self.boundaries, self.context)
+        entries = []
+        for i, b in enumerate(self.boundaries[1:], start=1):
+            if not b.native_available():
+                raise LettuceException(f"boundary '{type(b).__name__}' has no engine kernel")
+            entry = b.native_generator(i).plan_entry(flow)
+            if "field" in entry:
+                raise LettuceException("per-node equilibrium-boundary arguments are not supported "
+                                       "by the slab driver (use uniform velocity / pressure)")
+            entries.append(entry)
+        if ncm is not None:
+            ncm = ncm[..., h - 1:h + nzl + 1].permute(2, 1, 0).contiguous()
+            nsm = nsm[..., h - 1:h + nzl + 1].permute(0, 3, 2, 1).contiguous()
+        self.no_collision_mask, self.no_streaming_mask = ncm, nsm
         if engine is None:
             from ._native import Plan, LAYOUT_SLAB
             engine = Plan(type(flow.stencil).__name__, self.context.dtype, desc.kind,
-                          slab.local_resolution, layout=LAYOUT_SLAB, ghost_planes=1,
+                          slab.local_resolution, entries, layout=LAYOUT_SLAB, ghost_planes=1,
                           device=self.context.device)
+            if ncm is not None:
+                engine.set_masks(ncm, nsm)
+        elif entries:
+            engine.set_boundaries(entries, ncm, nsm, flow.units)      # test stand-ins
         self.engine = engine
         # [q, nx, ny, nzl + 2] incl. one ghost plane per side -> [q, nzl + 2, ny, nx]
         core = flow.f[..., h - 1:h + nzl + 1]

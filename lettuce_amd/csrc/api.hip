@@ -132,6 +132,8 @@ int check_boundary(const lt_plan *p, const lt_boundary_desc &b, int n_abb_before
         return fail(LT_ERR_INVALID, "anti-bounce-back outlet: axis %d side %d", b.axis, b.side);
       if (p->desc.shape[b.axis] < 2)
         return fail(LT_ERR_INVALID, "anti-bounce-back outlet needs >= 2 planes along its axis");
+      if (p->desc.ghost_planes && b.axis == 2)
+        return fail(LT_ERR_UNSUPPORTED, "an outlet along the decomposed (z) axis of a slab");
       if (n_abb_before > 0)
         return fail(LT_ERR_UNSUPPORTED,
                     "more than one AntiBounceBackOutlet per flow is not supported by the HIP engine");
@@ -366,8 +368,6 @@ int lt_plan_create(const lt_plan_desc *d, lt_plan **out) {
     return fail(LT_ERR_INVALID, "ghost_planes = %d needs the slab layout", d->ghost_planes);
   if (d->n_boundaries < 0 || d->n_boundaries > LT_MAX_BOUNDARIES)
     return fail(LT_ERR_UNSUPPORTED, "%d boundaries (max %d)", d->n_boundaries, LT_MAX_BOUNDARIES);
-  if (d->n_boundaries > 0 && d->layout != LT_LAYOUT_REFERENCE)
-    return fail(LT_ERR_UNSUPPORTED, "boundaries are supported in the reference layout only");
   for (int a = 0; a < unit.d; ++a)
     if (d->shape[a] < 1) return fail(LT_ERR_INVALID, "shape[%d] = %lld", a, (long long)d->shape[a]);
 
@@ -426,8 +426,6 @@ int lt_plan_destroy(lt_plan *p) {
 
 int lt_plan_set_masks(lt_plan *p, const uint8_t *ncm, const uint8_t *nsm, void *stream) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
-  if (p->desc.layout != LT_LAYOUT_REFERENCE)
-    return fail(LT_ERR_UNSUPPORTED, "masks are supported in the reference layout only");
   if (!ncm && !nsm) {
     if (p->desc.n_boundaries > 0)
       return fail(LT_ERR_INVALID, "a plan with boundaries needs a no_collision_mask");

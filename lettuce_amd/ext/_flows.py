@@ -154,7 +154,9 @@ class Obstacle(ExtFlow):
 
     def __init__(self, context: "Context", resolution: Union[int, List[int]], reynolds_number,
                  mach_number, domain_length_x, char_length=1, char_velocity=1,
-                 stencil: Optional["Stencil"] = None, equilibrium: Optional["Equilibrium"] = None):
+                 stencil: Optional["Stencil"] = None, equilibrium: Optional["Equilibrium"] = None,
+                 slab: Optional["ZSlab"] = None):
+        self.slab = slab          # multi-GPU extension, not in the reference (see _slab.py)
         self.char_length_lu = resolution[0] / domain_length_x * char_length
         self.char_length = char_length
         self.char_velocity = char_velocity
@@ -192,7 +194,10 @@ class Obstacle(ExtFlow):
 
     @property
     def grid(self):
-        axes = [self.units.convert_length_to_pu(torch.arange(n)) for n in self.resolution]
+        index = [torch.arange(n) for n in self.resolution]
+        if getattr(self, "slab", None) is not None:      # global z index of this rank's planes
+            index[2] = self.slab.z_indices()
+        axes = [self.units.convert_length_to_pu(i) for i in index]
         return torch.meshgrid(*axes, indexing="ij")
 
     @property

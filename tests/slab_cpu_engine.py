@@ -11,6 +11,29 @@ class OracleSlabEngine:
         self.lat = orc.LATTICES[lattice_name]
         self.e, self.w = orc.lattice_tensors(self.lat, dtype)
         self.collision = collision
+        self.entries, self.ncm, self.nsm = [], None, None
+
+    def set_boundaries(self, entries, ncm, nsm, units):
+        """entries as for lettuce_amd._native.Plan; masks in slab layout [nz+2, ny, nx] /
+        [q, nz+2, ny, nx]."""
+        self.entries, self.ncm, self.nsm = entries, ncm, nsm
+
+    def _boundaries(self, g, ncm):
+        """g: [q, x, y, zsub] (reference axis order), ncm: [x, y, zsub]; boundaries in index
+        order, each seeing the current field (lettuce/_simulation.py:186-188)."""
+        for idx, b in enumerate(self.entries, start=1):
+            if b["kind"] == "bounce_back":
+                new = orc.bounce_back(g, self.lat)
+            elif b["kind"] == "equilibrium":
+                feq = torch.tensor(b["feq"], dtype=g.dtype).reshape(-1, 1, 1, 1)
+                new = feq * torch.ones_like(g)
+            else:
+                direction = [0, 0, 0]
+                direction[b["axis"]] = b["side"]
+                new = orc.abb_outlet_inplace(g, orc.OracleBoundary("abb_outlet", direction=direction),
+                                             self.lat, self.e, self.w)
+            g = torch.where(ncm == idx, new, g)
+        return g
 
     def _collide(self, f, tau):
         if self.collision == "bgk":
@@ -29,11 +52,25 @@ class OracleSlabEngine:
             out[q] = moved[b - ez:e - ez]
         return out
 
+    def _collide_and_boundaries(self, planes, tau, b, e):
+        if self.ncm is None:
+            return self._collide(planes, tau)
+        g = planes.permute(0, 3, 2, 1).clone()                  # [q, x, y, zsub]
+        ncm = self.ncm[b:e].permute(2, 1, 0)
+        g = torch.where(ncm == 0, self._collide(g, tau), g)
+        return self._boundaries(g, ncm).permute(0, 3, 2, 1)
+
+    def _stream(self, f, b, e):
+        pulled = self._pull(f, b, e)
+        if self.nsm is None:
+            return pulled
+        return torch.where(self.nsm[:, b:e] == 1, f[:, b:e], pulled)
+
     def collide_planes(self, f, out, tau, b, e):
-        out[:, b:e] = self._collide(f[:, b:e], tau)
+        out[:, b:e] = self._collide_and_boundaries(f[:, b:e], tau, b, e)
 
     def stream_planes(self, f, out, b, e):
-        out[:, b:e] = self._pull(f, b, e)
+        out[:, b:e] = self._stream(f, b, e)
 
     def stream_collide_planes(self, f, out, tau, b, e):
-        out[:, b:e] = self._collide(self._pull(f, b, e), tau)
+        out[:, b:e] = self._collide_and_boundaries(self._stream(f, b, e), tau, b, e)

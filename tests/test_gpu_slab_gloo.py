@@ -79,3 +79,42 @@ def test_rccl_point_to_point_path_with_self_exchange(tmp_path):
     ref = orc.taylor_green(res, 400, 0.1, "D3Q19", torch.float32)
     ref.step(steps)
     np.testing.assert_allclose(got["f1"], ref.f.numpy(), rtol=0, atol=1e-5 * float(np.abs(ref.f.numpy()).max()))
+
+
+def _obstacle_worker(rank, world, port, name, steps, dtype_name, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import lettuce_amd as lt
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import golden
+    g = golden(name)
+    ctx = lt.Context("cuda:0", getattr(torch, dtype_name), use_native=True)
+    res = [int(r) for r in g["resolution"]]
+    slab = lt.ZSlab(res)
+    flow = lt.Obstacle(ctx, slab.extended_resolution, 100, 0.1, float(g["domain_length_x"]),
+                       stencil=lt.D3Q27(), slab=slab)
+    flow.mask = torch.tensor(g["obstacle_mask"])[:, :, slab.z_indices()]
+    flow.initialize()
+    sim = lt.SlabSimulation(flow, lt.KBCCollision(), slab)
+    sim(steps)
+    f1 = sim.gather_f()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "out.npz"), f1=f1.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,name,dtype_name,atol", [(1, "obstacle3d_d3q27_kbc_f64", "float64", 1e-11),
+                                                        (2, "obstacle3d_d3q27_kbc_f64", "float64", 1e-11),
+                                                        (3, "obstacle3d_d3q27_kbc_f32", "float32", 1e-5)])
+def test_obstacle_on_slabs_with_the_hip_engine(tmp_path, world, name, dtype_name, atol):
+    """Inlet + ABB outlet + sphere bounce-back on z-slabs (masked slab-layout kernels, ghost
+    exchange of bounce-back nodes' populations included) against the reference vectors."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import golden
+    port = 29900 + (os.getpid() % 1000) + world
+    mp.spawn(_obstacle_worker, args=(world, port, name, 8, dtype_name, str(tmp_path)), nprocs=world, join=True)
+    g, got = golden(name), np.load(tmp_path / "out.npz")
+    np.testing.assert_allclose(got["f1"], g["f8"], rtol=0, atol=atol * float(np.abs(g["f8"]).max()))
