@@ -51,6 +51,30 @@ def main(tag, nodes=256 ** 3, q=19, esize=4, workload="tgv3d_d3q19_bgk_f32_256")
               open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     for k in kernels:
         print(k["kernel"][:70], k["hbm_bytes_per_launch"], k["traffic_over_algorithmic"])
+    # optional extra passes (SQ issue mix, TCC hit/miss): medians per LBM kernel
+    extra = {}
+    for sub in ("pmc_SQ", "pmc_TCC"):
+        files = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+        if not files:
+            continue
+        acc = {}
+        for row in csv.DictReader(open(files[0])):
+            if "lbm_kernel" in row["Kernel_Name"]:
+                acc.setdefault(row["Kernel_Name"], {}).setdefault(row["Counter_Name"], []).append(
+                    float(row["Counter_Value"]))
+        for kname, counters in acc.items():
+            extra.setdefault(kname, {}).update({c: statistics.median(v) for c, v in counters.items()})
+    if extra:
+        for kname, c in extra.items():
+            if "SQ_WAVES" in c and c["SQ_WAVES"]:
+                c["valu_insts_per_wave"] = round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1)
+                c["vmem_rd_per_wave"] = round(c["SQ_INSTS_VMEM_RD"] / c["SQ_WAVES"], 2)
+                c["vmem_wr_per_wave"] = round(c["SQ_INSTS_VMEM_WR"] / c["SQ_WAVES"], 2)
+            if "TCC_HIT_sum" in c:
+                c["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
+        json.dump({"tag": tag, "note": "medians over the sampled launches; rocprofv3 --pmc, separate "
+                   "passes for SQ and TCC (tools/gpu_round.sh)", "kernels": extra},
+                  open(os.path.join(dst, f"{tag}_pmc_sq_tcc.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
