@@ -248,7 +248,7 @@ class DoublyPeriodicShear2D(ExtFlow):
         self.initialize_fneq = initialize_fneq
         self.initial_perturbation_magnitude = initial_perturbation_magnitude
         self.shear_layer_width = shear_layer_width
-        self.stencil = D2Q9() if stencil is None else stencil
+        self.stencil = D2Q9() if stencil is None else (stencil() if callable(stencil) else stencil)
         super().__init__(context, resolution, reynolds_number, mach_number, self.stencil,
                          equilibrium)
 
