@@ -408,3 +408,28 @@ def test_long_run_energy_decay_fp32_tracks_fp64():
         assert torch.isfinite(flow.f).all()
     assert len(series["f64"]) == 11 and (np.diff(series["f64"]) < 0).all() and (np.diff(series["f32"]) < 0).all()
     np.testing.assert_allclose(series["f32"], series["f64"], rtol=1e-4)
+
+
+def test_integration_md_ctypes_stub_steps_a_simulation():
+    """The reference-side ctypes stub printed in INTEGRATION.md (section B) is executed as written
+    -- only the library path is pointed at the in-tree build -- and plugged into the swap point
+    `Simulation._collide_and_stream` of a non-native simulation on a GPU tensor."""
+    import os
+    import re
+    from conftest import ROOT
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# lettuce/hip_native.py.*?)```", text, re.S).group(1)
+    from lettuce_amd._native import library_path
+    code = code.replace('ctypes.CDLL("liblettuce_hip.so")', f'ctypes.CDLL("{library_path()}")')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    g = golden("tgv3d_d3q19_bgk_16_f32")
+    c = lt.Context("cuda:0", torch.float32, use_native=False)
+    flow = lt.TaylorGreenVortex(c, [16] * 3, 1600, 0.1, lt.D3Q19())
+    sim = lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])
+    assert sim._native is None
+    sim._collide_and_stream = ns["make_native_kernel"](sim)          # lettuce/_simulation.py:148
+    sim(10)
+    torch.cuda.synchronize()
+    assert flow.i == 10
+    np.testing.assert_allclose(flow.f.cpu().numpy(), g["f10"], rtol=0, atol=1e-5 * float(np.abs(g["f10"]).max()))
