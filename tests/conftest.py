@@ -43,3 +43,22 @@ def unpack_nsm(g):
 
 
 TORCH_DT = {"f64": torch.float64, "f32": torch.float32}
+
+
+@pytest.fixture(scope="session")
+def engine_library():
+    """Path of the in-tree HIP engine library; built on demand (hipcc cross-compiles without a
+    GPU) so that a fresh checkout, where the git-ignored .so does not exist yet, still passes."""
+    from lettuce_amd import _native
+    if not os.path.exists(_native.library_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _native.library_path()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _engine_library_for_gpu_runs(request):
+    """On a GPU box make sure the in-tree library exists before any parity test runs (the tests
+    build it; the product itself never does -- a missing library is an error there)."""
+    if torch.cuda.is_available():
+        request.getfixturevalue("engine_library")

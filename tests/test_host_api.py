@@ -250,7 +250,7 @@ def test_torch_gradient_orders():
 
 
 # ------------------------------------------------------------------ C ABI (no compute calls)
-def test_library_exports_every_declared_symbol():
+def test_library_exports_every_declared_symbol(engine_library):
     from lettuce_amd import _native
     header = open(os.path.join(ROOT, "include", "lettuce_hip.h")).read()
     declared = set(re.findall(r"\b(lt_[a-z_]+)\s*\(", header))
@@ -280,7 +280,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.lt_plan_destroy(None) == 0
 
 
-def test_native_context_never_falls_back(monkeypatch):
+def test_native_context_never_falls_back(monkeypatch, engine_library):
     """use_native with no engine library must raise, not run torch ops."""
     from lettuce_amd import _native
     flow = lt.TaylorGreenVortex(ctx(), [8, 8], 10, 0.05, lt.D2Q9())
