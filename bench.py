@@ -111,11 +111,31 @@ def traffic_from_profile(kernel_name):
     return None
 
 
+def ensure_library(local_rank):
+    """The in-tree engine library normally travels with the tree; on a fresh tree local rank 0
+    builds it (hipcc, ~1 min) while the other ranks wait for the file."""
+    from lettuce_amd import _native
+    path = _native.library_path()
+    if os.path.exists(path):
+        return
+    if local_rank == 0:
+        import __graft_entry__
+        __graft_entry__.build()
+        return
+    deadline = time.time() + 900
+    while not os.path.exists(path):
+        if time.time() > deadline:
+            raise SystemExit(f"{path} was not built")
+        time.sleep(2)
+    time.sleep(2)          # let the linker finish writing
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ensure_library(local_rank)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
