@@ -51,8 +51,9 @@ enum lt_status {
   LT_ERR_ALLOC = 4
 };
 
-/* lettuce/ext/_stencil/d2q9.py:8-10, d3q19.py:8-13, d3q27.py:8-12 (same velocity order) */
-enum lt_stencil { LT_D2Q9 = 0, LT_D3Q19 = 1, LT_D3Q27 = 2 };
+/* lettuce/ext/_stencil/d2q9.py:8-10, d3q19.py:8-13, d3q27.py:8-12, d1q3.py:8-10, d3q15.py:8-13
+ * (same velocity order) */
+enum lt_stencil { LT_D2Q9 = 0, LT_D3Q19 = 1, LT_D3Q27 = 2, LT_D1Q3 = 3, LT_D3Q15 = 4 };
 /* AT_DISPATCH_FLOATING_TYPES, lettuce/cuda_native/_template.py:357 */
 enum lt_dtype { LT_F32 = 0, LT_F64 = 1 };
 /* lettuce/ext/_collision/no_collision.py:9-17, bgk_collision.py:12-35, kbc_collision.py:11-166 */
@@ -88,9 +89,9 @@ typedef struct lt_plan_desc {
   int32_t collision;       /* lt_collision */
   int32_t layout;          /* lt_layout */
   int32_t ghost_planes;    /* 0, or 1 (LT_LAYOUT_SLAB only) */
-  int32_t dims;            /* 2 or 3; must match the stencil */
+  int32_t dims;            /* 1, 2 or 3; must match the stencil */
   int32_t n_boundaries;    /* 0 .. LT_MAX_BOUNDARIES */
-  int64_t shape[3];        /* logical resolution (nx, ny, nz); nz = 1 in 2-D.  With ghost
+  int64_t shape[3];        /* logical resolution (nx, ny, nz); unused trailing entries = 1.  With ghost
                               planes this is the rank-local slab WITHOUT the ghosts. */
   lt_boundary_desc boundaries[LT_MAX_BOUNDARIES];
 } lt_plan_desc;

@@ -27,7 +27,7 @@ LT_ABI_VERSION = 1
 LT_MAX_BOUNDARIES = 7
 LT_MAX_Q = 27
 
-STENCIL_IDS = {"D2Q9": 0, "D3Q19": 1, "D3Q27": 2}
+STENCIL_IDS = {"D2Q9": 0, "D3Q19": 1, "D3Q27": 2, "D1Q3": 3, "D3Q15": 4}
 DTYPE_IDS = {torch.float32: 0, torch.float64: 1}
 COLLISION_IDS = {"none": 0, "bgk": 1, "kbc": 2}
 BOUNDARY_KINDS = {"bounce_back": 1, "equilibrium": 2, "abb_outlet": 3}

@@ -3,8 +3,8 @@
 Public surface of lettuce/_stencil.py:12-46 and lettuce/ext/_stencil/*.py: classes
 ``D1Q3, D2Q9, D3Q15, D3Q19, D3Q27`` with list attributes ``e, w, opposite`` and
 ``cs = 1/sqrt(3)``; the velocity ORDER is part of the contract (it is the q index of
-``flow.f``) and is identical to the reference's.  The HIP engine has kernels for D2Q9,
-D3Q19 and D3Q27 (lettuce_amd/csrc/lattice.hpp holds the same tables).
+``flow.f``) and is identical to the reference's.  The HIP engine has kernels for all five
+(lettuce_amd/csrc/lattice.hpp holds the same tables).
 """
 from abc import ABC
 from typing import List

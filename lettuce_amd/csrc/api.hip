@@ -37,13 +37,17 @@ struct Unit {
   int q, d;
 };
 
-const Unit kUnits[3][2] = {
+const Unit kUnits[5][2] = {
     {{lt::step_d2q9_f32, lt::aux_d2q9_f32, lt::name_d2q9_f32, 9, 2},
      {lt::step_d2q9_f64, lt::aux_d2q9_f64, lt::name_d2q9_f64, 9, 2}},
     {{lt::step_d3q19_f32, lt::aux_d3q19_f32, lt::name_d3q19_f32, 19, 3},
      {lt::step_d3q19_f64, lt::aux_d3q19_f64, lt::name_d3q19_f64, 19, 3}},
     {{lt::step_d3q27_f32, lt::aux_d3q27_f32, lt::name_d3q27_f32, 27, 3},
      {lt::step_d3q27_f64, lt::aux_d3q27_f64, lt::name_d3q27_f64, 27, 3}},
+    {{lt::step_d1q3_f32, lt::aux_d1q3_f32, lt::name_d1q3_f32, 3, 1},
+     {lt::step_d1q3_f64, lt::aux_d1q3_f64, lt::name_d1q3_f64, 3, 1}},
+    {{lt::step_d3q15_f32, lt::aux_d3q15_f32, lt::name_d3q15_f32, 15, 3},
+     {lt::step_d3q15_f64, lt::aux_d3q15_f64, lt::name_d3q15_f64, 15, 3}},
 };
 
 constexpr int kReduceBlocks = 1024;
@@ -92,6 +96,7 @@ struct lt_plan {
 namespace {
 
 int mem_axis_of(const lt_plan *p, int logical_axis) {
+  if (p->unit.d == 1) return 0;
   if (p->unit.d == 2) return logical_axis == 0 ? 1 : 0;
   return p->desc.layout == LT_LAYOUT_REFERENCE ? 2 - logical_axis : logical_axis;
 }
@@ -159,7 +164,9 @@ lt::QList crossing_of(int logical_axis, int dir) {
 lt::QList crossing(const lt_plan *p, int dir) {
   const int axis = p->unit.d == 2 ? 0 : (p->desc.layout == LT_LAYOUT_REFERENCE ? 0 : 2);
   switch (p->desc.stencil) {
+    case LT_D1Q3: return crossing_of<lt::D1Q3>(0, dir);
     case LT_D2Q9: return crossing_of<lt::D2Q9>(axis, dir);
+    case LT_D3Q15: return crossing_of<lt::D3Q15>(axis, dir);
     case LT_D3Q19: return crossing_of<lt::D3Q19>(axis, dir);
     default: return crossing_of<lt::D3Q27>(axis, dir);
   }
@@ -354,12 +361,12 @@ int lt_plan_create(const lt_plan_desc *d, lt_plan **out) {
   *out = nullptr;
   if (d->abi_version != LT_ABI_VERSION)
     return fail(LT_ERR_INVALID, "ABI version %d, library is %d", d->abi_version, LT_ABI_VERSION);
-  if (d->stencil < 0 || d->stencil > 2) return fail(LT_ERR_UNSUPPORTED, "stencil %d", d->stencil);
+  if (d->stencil < 0 || d->stencil > 4) return fail(LT_ERR_UNSUPPORTED, "stencil %d", d->stencil);
   if (d->dtype < 0 || d->dtype > 1) return fail(LT_ERR_UNSUPPORTED, "dtype %d (fp32/fp64 only)", d->dtype);
   if (d->collision < 0 || d->collision > 2) return fail(LT_ERR_UNSUPPORTED, "collision %d", d->collision);
   const Unit unit = kUnits[d->stencil][d->dtype];
   if (d->dims != unit.d) return fail(LT_ERR_INVALID, "stencil is %d-dimensional, dims = %d", unit.d, d->dims);
-  if (d->collision == LT_COLLISION_KBC && d->stencil == LT_D3Q19)
+  if (d->collision == LT_COLLISION_KBC && d->stencil != LT_D2Q9 && d->stencil != LT_D3Q27)
     return fail(LT_ERR_UNSUPPORTED, "KBC collision exists for D2Q9 and D3Q27 only");
   if (d->layout != LT_LAYOUT_REFERENCE && d->layout != LT_LAYOUT_SLAB)
     return fail(LT_ERR_INVALID, "layout %d", d->layout);
@@ -377,7 +384,8 @@ int lt_plan_create(const lt_plan_desc *d, lt_plan **out) {
   p->unit = unit;
   p->esize = d->dtype == LT_F32 ? 4 : 8;
   long long e0, e1, e2;
-  if (unit.d == 2) { e0 = d->shape[1]; e1 = d->shape[0]; e2 = 1; }
+  if (unit.d == 1) { e0 = d->shape[0]; e1 = 1; e2 = 1; }
+  else if (unit.d == 2) { e0 = d->shape[1]; e1 = d->shape[0]; e2 = 1; }
   else if (d->layout == LT_LAYOUT_REFERENCE) { e0 = d->shape[2]; e1 = d->shape[1]; e2 = d->shape[0]; }
   else { e0 = d->shape[0]; e1 = d->shape[1]; e2 = d->shape[2] + 2 * d->ghost_planes; }
   if (e0 * e1 * e2 >= (1ll << 31)) {

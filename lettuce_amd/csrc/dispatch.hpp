@@ -48,6 +48,10 @@ typedef const char *(*NameFn)(const StepArgs &);
   int aux_##tag(const AuxArgs &);         \
   const char *name_##tag(const StepArgs &);
 
+LT_DECLARE_UNIT(d1q3_f32)
+LT_DECLARE_UNIT(d1q3_f64)
+LT_DECLARE_UNIT(d3q15_f32)
+LT_DECLARE_UNIT(d3q15_f64)
 LT_DECLARE_UNIT(d2q9_f32)
 LT_DECLARE_UNIT(d2q9_f64)
 LT_DECLARE_UNIT(d3q19_f32)

@@ -79,7 +79,8 @@ def test_kbc_d2q9_one_step_on_perturbed_state():
 
 
 @pytest.mark.parametrize("lat,res", [("D2Q9", [7, 5]), ("D3Q19", [6, 5, 7]), ("D3Q27", [3, 4, 5]),
-                                     ("D3Q19", [4, 4, 8]), ("D2Q9", [1, 8]), ("D3Q27", [2, 1, 4])])
+                                     ("D3Q19", [4, 4, 8]), ("D2Q9", [1, 8]), ("D3Q27", [2, 1, 4]),
+                                     ("D1Q3", [37]), ("D1Q3", [2]), ("D3Q15", [5, 6, 7]), ("D3Q15", [8, 8, 8])])
 @pytest.mark.parametrize("dt", ["f64", "f32"])
 def test_ragged_and_tiny_grids_against_oracle(lat, res, dt):
     """Sizes the 16-byte vector path cannot take, and sizes where every node wraps."""
@@ -98,12 +99,12 @@ def test_ragged_and_tiny_grids_against_oracle(lat, res, dt):
             assert_close(got, sim.f.numpy(), dt)
 
 
-@pytest.mark.parametrize("lat", ["D2Q9", "D3Q19", "D3Q27"])
+@pytest.mark.parametrize("lat", ["D1Q3", "D2Q9", "D3Q15", "D3Q19", "D3Q27"])
 def test_streaming_is_exact_and_periodic(lat):
     """Tagged populations: S^n with n = grid size returns to the start; one step equals
     torch.roll by +e_q (tests/native/test_native_streaming.py)."""
     L = orc.LATTICES[lat]
-    res = [8, 8] if L.d == 2 else [8, 8, 8]
+    res = [8] * L.d
     f0 = torch.arange(L.q * int(np.prod(res)), dtype=torch.float32).reshape([L.q] + res)
     plan = plan_for(lat, torch.float32, "none", res)
     sim = orc.OracleSimulation(L, f0.clone(), "none", 1.0)
@@ -322,7 +323,8 @@ def _random_state(L, res, dtype, seed):
     return (w * (1 + 0.2 * torch.rand([L.q] + res, generator=g, dtype=torch.float64))).to(dtype)
 
 
-@pytest.mark.parametrize("lat,res", [("D2Q9", [12, 10]), ("D3Q19", [8, 6, 10]), ("D3Q27", [6, 8, 7])])
+@pytest.mark.parametrize("lat,res", [("D2Q9", [12, 10]), ("D3Q19", [8, 6, 10]), ("D3Q27", [6, 8, 7]),
+                                     ("D1Q3", [40]), ("D3Q15", [6, 7, 8])])
 @pytest.mark.parametrize("dt", ["f64", "f32"])
 def test_random_masks_bounce_back_equilibrium_and_sparse_no_streaming(lat, res, dt):
     """Random no_collision_mask with two boundary kinds + random sparse no_streaming bits on fluid
@@ -353,7 +355,8 @@ def test_random_masks_bounce_back_equilibrium_and_sparse_no_streaming(lat, res, 
 
 
 @pytest.mark.parametrize("lat,res,axis,side", [("D2Q9", [10, 8], 1, -1), ("D3Q19", [8, 6, 7], 0, 1),
-                                               ("D3Q27", [6, 7, 8], 2, 1)])
+                                               ("D3Q27", [6, 7, 8], 2, 1), ("D1Q3", [24], 0, 1),
+                                               ("D3Q15", [7, 6, 8], 1, 1)])
 def test_abb_outlet_after_lower_index_boundaries(lat, res, axis, side):
     """An AntiBounceBackOutlet whose index is HIGHER than a bounce-back and an equilibrium
     boundary that touch the outlet plane and the plane next to it: the outlet must see the

@@ -67,7 +67,7 @@ def test_stencil_properties_and_tables(cls):
 def test_csrc_lattice_tables_match_python():
     """lettuce_amd/csrc/lattice.hpp holds the same velocity order as the Python stencils."""
     text = open(os.path.join(ROOT, "lettuce_amd", "csrc", "lattice.hpp")).read()
-    for cls in (lt.D2Q9, lt.D3Q19, lt.D3Q27):
+    for cls in (lt.D1Q3, lt.D2Q9, lt.D3Q15, lt.D3Q19, lt.D3Q27):
         s = cls()
         block = text.split(f"struct {cls.__name__} ")[1].split("static constexpr double W")[0]
         nums = [int(v) for v in re.findall(r"-?\d+", block.split("E[")[1].split("=", 1)[1])]
@@ -291,9 +291,14 @@ def test_native_context_never_falls_back(monkeypatch, engine_library):
         lt.Simulation(flow, lt.BGKCollision(0.8), [])
     # and a component without kernels is refused loudly
     monkeypatch.undo()
-    flow3 = UniformFlow(ctx(), [4, 4, 4], 1, 0.01, lt.D3Q15())
+    class D2Q5(lt.Stencil):                     # a lattice the engine has no kernels for
+        def __init__(self):
+            self.e = [[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]]
+            self.w = [1 / 3] + [1 / 6] * 4
+            self.opposite = [0, 3, 4, 1, 2]
+    flow3 = UniformFlow(ctx(), [4, 4], 1, 0.01, D2Q5())
     flow3.context.use_native = True
-    with pytest.raises(lt.LettuceException, match="D3Q15"):
+    with pytest.raises(lt.LettuceException, match="D2Q5"):
         lt.Simulation(flow3, lt.BGKCollision(0.8), [])
 
 
