@@ -147,6 +147,14 @@ int lt_stream_collide_planes(lt_plan *plan, const void *fstar_dev, void *fstar_o
 int lt_stream_collide_plane_pair(lt_plan *plan, const void *fstar_dev, void *fstar_out_dev,
                                  double tau, int64_t first, int64_t second, void *stream);
 
+/* As lt_stream_collide_plane_pair, and in the same launch the crossing populations of plane
+ * `first` (velocity component -1 along the slowest axis) are packed into pack_first_dev and those
+ * of plane `second` (+1) into pack_second_dev, in the layout of lt_slab_pack (first == second is
+ * allowed: a one-plane slab). */
+int lt_stream_collide_plane_pair_packed(lt_plan *plan, const void *fstar_dev, void *fstar_out_dev,
+                                        double tau, int64_t first, int64_t second,
+                                        void *pack_first_dev, void *pack_second_dev, void *stream);
+
 /* Halo packing for the slab driver (no reference counterpart: the reference is single-GPU).
  * direction = +1 / -1 selects the populations whose velocity component along the slowest memory
  * axis is +1 / -1 (5 of 19 for D3Q19, 9 of 27 for D3Q27), in ascending q.

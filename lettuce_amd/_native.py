@@ -71,6 +71,7 @@ SYMBOLS = {
     "lt_stream_planes": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "lt_stream_collide_planes": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _i64, _i64, _vp]),
     "lt_stream_collide_plane_pair": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _i64, _i64, _vp]),
+    "lt_stream_collide_plane_pair_packed": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _i64, _i64, _vp, _vp, _vp]),
     "lt_slab_crossing": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "lt_slab_pack": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "lt_slab_unpack": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
@@ -346,6 +347,12 @@ class Plan:
     def stream_collide_plane_pair(self, f, out, tau, first, second):
         self._check(self.lib.lt_stream_collide_plane_pair(self._handle, _ptr(f), _ptr(out), float(tau),
                                                           int(first), int(second), _stream_handle()))
+
+    @_on_device
+    def stream_collide_plane_pair_packed(self, f, out, tau, first, second, pack_first, pack_second):
+        self._check(self.lib.lt_stream_collide_plane_pair_packed(
+            self._handle, _ptr(f), _ptr(out), float(tau), int(first), int(second), _ptr(pack_first),
+            _ptr(pack_second), _stream_handle()))
 
     @_on_device
     def run(self, a, b, tau, n_steps, from_fstar=False):

@@ -193,15 +193,16 @@ class SlabSimulation:
         else:
             buf[self.up if direction > 0 else self.down, plane] = src
 
-    def _exchange(self, buf: torch.Tensor):
+    def _exchange(self, buf: torch.Tensor, packed: bool = False):
         """Fill the ghost planes of ``buf`` (post-collision populations) from the neighbours:
         the e_z = -1 populations of my plane 1 go to the lower neighbour's upper ghost plane, the
         e_z = +1 populations of my top plane to the upper neighbour's lower ghost plane.  One
         packed message per direction.  Returns a callable that completes the exchange (waits
         for the transfers and unpacks)."""
         nzl, s = self.nzl, self.slab
-        self._pack(buf, 1, -1, self._send_down)
-        self._pack(buf, nzl, +1, self._send_up)
+        if not packed:
+            self._pack(buf, 1, -1, self._send_down)
+            self._pack(buf, nzl, +1, self._send_up)
         if s.world_size == 1 and not self._force_p2p:
             recv_down, recv_up, reqs = self._send_down, self._send_up, []
         else:
@@ -226,13 +227,17 @@ class SlabSimulation:
         return finish
 
     # ---- stepping --------------------------------------------------------------------------------
-    def _boundary_planes(self, cur, nxt, tau):
-        if self.nzl > 1 and hasattr(self.engine, "stream_collide_plane_pair"):
-            self.engine.stream_collide_plane_pair(cur, nxt, tau, 1, self.nzl)   # one launch
-            return
+    def _boundary_planes(self, cur, nxt, tau) -> bool:
+        """Stream-collide planes 1 and nz_local; returns True when the launch also packed the
+        crossing populations into the send buffers."""
+        if hasattr(self.engine, "stream_collide_plane_pair_packed"):
+            self.engine.stream_collide_plane_pair_packed(cur, nxt, tau, 1, self.nzl,
+                                                         self._send_down, self._send_up)
+            return True
         self.engine.stream_collide_planes(cur, nxt, tau, 1, 2)
         if self.nzl > 1:
             self.engine.stream_collide_planes(cur, nxt, tau, self.nzl, self.nzl + 1)
+        return False
 
     def _fused_step(self, cur, nxt, tau):
         """One stream-collide of the slab.  With overlap the two boundary planes, the halo packing,
@@ -244,14 +249,14 @@ class SlabSimulation:
             compute = torch.cuda.current_stream()
             self._comm.wait_stream(compute)          # previous step complete (it read nxt)
             with torch.cuda.stream(self._comm):
-                self._boundary_planes(cur, nxt, tau)
-                self._exchange(nxt)()
+                packed = self._boundary_planes(cur, nxt, tau)
+                self._exchange(nxt, packed)()
             if nzl > 2:
                 eng.stream_collide_planes(cur, nxt, tau, 2, nzl)
             compute.wait_stream(self._comm)
         else:
-            self._boundary_planes(cur, nxt, tau)
-            finish = self._exchange(nxt)
+            packed = self._boundary_planes(cur, nxt, tau)
+            finish = self._exchange(nxt, packed)
             if nzl > 2:
                 eng.stream_collide_planes(cur, nxt, tau, 2, nzl)
             finish()

@@ -204,7 +204,7 @@ int resolve_tune(const lt_plan *p, int wide) {
 }
 
 int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long pb, long long pe,
-         void *stream, long long stride = 1) {
+         void *stream, long long stride = 1, void *pack_lo = nullptr, void *pack_hi = nullptr) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (!in || !out) return fail(LT_ERR_INVALID, "null population buffer");
   if (in == out) return fail(LT_ERR_INVALID, "in-place operation is not supported (in == out)");
@@ -233,6 +233,8 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.shift = a.wide ? p->shift : 0;
   a.tune = resolve_tune(p, a.wide);
   a.stream = static_cast<hipStream_t>(stream);
+  a.pack_lo = pack_lo; a.pack_hi = pack_hi;
+  a.pack_lo_plane = (int)pb; a.pack_hi_plane = (int)(pb + stride * (a.planes - 1));
   const int r = p->unit.step(a);
   if (r == lt::kNoKernel)
     return fail(LT_ERR_UNSUPPORTED, "no kernel for layout %d collision %d mode %d masked %d",
@@ -486,6 +488,17 @@ int lt_stream_collide_plane_pair(lt_plan *p, const void *f, void *o, double tau,
                                  int64_t second, void *s) {
   if (second <= first) return fail(LT_ERR_INVALID, "plane pair (%lld, %lld)", (long long)first, (long long)second);
   return step(p, lt::kFused, f, o, tau, first, second + 1, s, second - first);
+}
+
+int lt_stream_collide_plane_pair_packed(lt_plan *p, const void *f, void *o, double tau,
+                                        int64_t first, int64_t second, void *pack_first,
+                                        void *pack_second, void *s) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (second < first) return fail(LT_ERR_INVALID, "plane pair (%lld, %lld)", (long long)first, (long long)second);
+  if (!pack_first || !pack_second) return fail(LT_ERR_INVALID, "null pack buffer");
+  if (p->desc.layout != LT_LAYOUT_SLAB) return fail(LT_ERR_UNSUPPORTED, "fused packing needs the slab layout");
+  const long long stride = second > first ? second - first : 1;
+  return step(p, lt::kFused, f, o, tau, first, second + 1, s, stride, pack_first, pack_second);
 }
 
 int lt_run(lt_plan *p, void *a, void *b, double tau, int64_t n, void *s, int32_t *r) {

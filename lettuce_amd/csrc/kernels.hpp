@@ -67,6 +67,11 @@ struct KParams {
   const unsigned *nsm_bits;  // [N] bit q set: population q keeps its value (or null)
   const BoundaryTable<T> *bt;
   int nb;
+  // slab boundary launch (PACK kernels): the crossing populations of plane pack_lo_plane
+  // (e along a2 = -1) / pack_hi_plane (+1) are also written to contiguous send buffers
+  // [k][n1*n0], k = rank of q among the populations with that e (ascending q)
+  T *pack_lo, *pack_hi;
+  int pack_lo_plane, pack_hi_plane;
 };
 
 // ---- constants the reference builds from cs = 1/np.sqrt(3.0) (lettuce/_stencil.py:17) ----
@@ -533,8 +538,17 @@ __device__ __forceinline__ void abb_outlet(const KParams<T> &p, int slot, int c0
 // TUNE bit 0: nontemporal loads, bit 1: nontemporal stores.  One thread per VEC nodes, the grid
 // covers the work exactly (a capped grid with a grid-stride loop measured 7 % slower and cost
 // 20-30 VGPRs in the KBC kernels).
+// number of populations q' < q with the same velocity component along memory axis a2
+template <class S, int LAYOUT, int q>
+constexpr int crossing_rank() {
+  int r = 0;
+  for (int k = 0; k < q; ++k)
+    if (MemMap<S, LAYOUT>::e(k, 2) == MemMap<S, LAYOUT>::e(q, 2)) ++r;
+  return r;
+}
+
 template <typename T, class S, int LAYOUT, int COLL, bool STREAM, bool COLLIDE, bool MASKED,
-          int VEC, int SHIFT, int TUNE = 0>
+          int VEC, int SHIFT, int TUNE = 0, bool PACK = false>
 __device__ __forceinline__ void lbm_body(const KParams<T> &p) {
   const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= p.nvec_total) return;
@@ -608,13 +622,30 @@ __device__ __forceinline__ void lbm_body(const KParams<T> &p) {
     constexpr int q = decltype(qc)::value;
     vstore<T, VEC, (TUNE & 2) != 0>(p.out + (long long)q * p.N + own, f[q]);
   });
+  if constexpr (PACK) {
+    // halo packing fused into the boundary-plane launch of the slab driver (saves two pack
+    // launches on the critical path of the exchange)
+    using M = MemMap<S, LAYOUT>;
+    const unsigned in_plane = (unsigned)c1 * (unsigned)p.n0 + (unsigned)c0;
+    const unsigned plane_nodes = (unsigned)p.n1 * (unsigned)p.n0;
+    static_for<S::Q>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int e2 = M::e(q, 2);
+      if constexpr (e2 != 0) {
+        constexpr int rank = crossing_rank<S, LAYOUT, q>();
+        T *buf = e2 < 0 ? p.pack_lo : p.pack_hi;
+        const int plane = e2 < 0 ? p.pack_lo_plane : p.pack_hi_plane;
+        if (c2 == plane) vstore<T, VEC, false>(buf + (size_t)rank * plane_nodes + in_plane, f[q]);
+      }
+    });
+  }
   }
 }
 
 template <typename T, class S, int LAYOUT, int COLL, bool STREAM, bool COLLIDE, bool MASKED,
-          int VEC, int SHIFT, int TUNE = 0>
+          int VEC, int SHIFT, int TUNE = 0, bool PACK = false>
 __global__ void __launch_bounds__(kThreads) lbm_kernel(const KParams<T> p) {
-  lbm_body<T, S, LAYOUT, COLL, STREAM, COLLIDE, MASKED, VEC, SHIFT, TUNE>(p);
+  lbm_body<T, S, LAYOUT, COLL, STREAM, COLLIDE, MASKED, VEC, SHIFT, TUNE, PACK>(p);
 }
 
 // ---- auxiliary kernels --------------------------------------------------------------------
