@@ -296,13 +296,59 @@ __device__ __forceinline__ void moments(const T (&f)[S::Q][VEC], T &rho, T (&j)[
   });
 }
 
+// value barrier: the optimiser may not assume anything about x afterwards
+__device__ __forceinline__ float launder(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ double launder(double x) { asm volatile("" : "+v"(x)); return x; }
+
+// u.u summed in the logical order x, y, z with separately rounded products and sums -- what
+// torch's einsum("d...,d...->...") produces on the CPU (checked bit for bit against the reference's
+// vectors), so that feq(rho, u) is reproduced exactly, not just to an ulp
+template <class S, int LAYOUT, typename T>
+__device__ __forceinline__ T square_norm(const T (&u)[3]) {
+#pragma clang fp contract(off)
+  using M = MemMap<S, LAYOUT>;
+  T r = u[M::memory(0)] * u[M::memory(0)];
+  if constexpr (S::D > 1) r = r + u[M::memory(1)] * u[M::memory(1)];
+  if constexpr (S::D > 2) r = r + u[M::memory(2)] * u[M::memory(2)];
+  return r;
+}
+
+// x / D for the constants D = 2 cs^2 and cs^2 of the equilibrium.  The reference divides the fp32
+// field by the python double cast to fp32 (D_f = 0.66666669 / 0.33333334, 3e-8 above 2/3 and 1/3);
+// that systematic 3e-8 is what makes its fp32 kinetic energy drift by -1.1e-7 per step against its
+// fp64 run.  To track the reference's fp32 path (not just fp64 truth) the same quotient is formed:
+// x / D_f = x * (hi + lo) with hi + lo = 1 / D_f to double precision, evaluated in double-float
+// arithmetic (the rounding error of x * hi is recovered with an FMA): four instructions instead of
+// a ~10-instruction IEEE division, and the same correctly rounded quotient in all but rare ties.
+template <int WHICH>   // 0: D = 2 cs^2, 1: D = cs^2
+__device__ __forceinline__ float div_cs(float x) {
+  constexpr double d = WHICH == 0 ? 2.0 * kCs2 : kCs2;
+  constexpr double inv = 1.0 / (double)(float)d;
+  constexpr float hi = (float)inv;
+  constexpr float lo = (float)(inv - (double)hi);
+  // the rounded product is hidden from the optimiser: hipcc otherwise re-fuses the final sum with
+  // the multiplication (p + c -> fma(x, hi, c)) and the recovered rounding error counts twice
+  const float p = launder(x * hi);
+  const float err = fmaf(x, hi, -p);
+  return p + fmaf(x, lo, err);
+}
+template <int WHICH>
+__device__ __forceinline__ double div_cs(double x) {
+  constexpr double d = WHICH == 0 ? 2.0 * kCs2 : kCs2;
+  return x * (1.0 / d);
+}
+
 // QuadraticEquilibrium (lettuce/ext/_equilibrium/quadratic_equilibrium.py:15-24), u along
 // memory axes (the dot products are invariant under the axis permutation)
 template <typename T, class S, int LAYOUT, int q>
 __device__ __forceinline__ T feq_q(T rho, const T (&u)[3], T uxu) {
+  // every operation rounds separately, as the reference's whole-field torch ops do: with
+  // mul+add fused the 1-ulp differences are correlated with the sign of e.u and halve the
+  // (reference-inherent) fp32 momentum deficit of the equilibrium
+#pragma clang fp contract(off)
   const T exu = dot_e<S, LAYOUT, q>(u);
-  const T a = (T(2) * exu - uxu) * T(1.0 / (2.0 * kCs2));
-  const T b = exu * T(1.0 / kCs2);
+  const T a = div_cs<0>(T(2) * exu - uxu);
+  const T b = div_cs<1>(exu);
   return T(S::W[q]) * (rho * (a + T(0.5) * (b * b) + T(1)));
 }
 
@@ -312,8 +358,9 @@ __device__ __forceinline__ void collide_bgk(T (&f)[S::Q][VEC], T tau_inv) {
   T rho, j[3], u[3];
   moments<T, S, LAYOUT, VEC, k>(f, rho, j);
   u[0] = j[0] / rho; u[1] = j[1] / rho; u[2] = j[2] / rho;
-  const T uxu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+  const T uxu = square_norm<S, LAYOUT>(u);
   static_for<S::Q>([&](auto qc) {
+#pragma clang fp contract(off)
     constexpr int q = decltype(qc)::value;
     const T feq = feq_q<T, S, LAYOUT, q>(rho, u, uxu);
     f[q][k] = f[q][k] - tau_inv * (f[q][k] - feq);
@@ -397,11 +444,6 @@ __device__ __forceinline__ KbcS<T, S> kbc_s(const G &g) {
 __device__ __forceinline__ float kbc_ratio(float x, float y) { return x * __builtin_amdgcn_rcpf(y); }
 __device__ __forceinline__ double kbc_ratio(double x, double y) { return x / y; }
 
-// value barrier: the optimiser may not assume anything about x afterwards (used to make it
-// re-evaluate cheap expressions instead of keeping Q results alive in registers)
-__device__ __forceinline__ float launder(float x) { asm volatile("" : "+v"(x)); return x; }
-__device__ __forceinline__ double launder(double x) { asm volatile("" : "+v"(x)); return x; }
-
 // LEAN = false: feq[Q] is evaluated once and kept (D3Q27 fp32: 139 VGPRs, 3 waves/SIMD).
 // LEAN = true:  feq_q is re-evaluated in each of the three passes over q (same expression, same
 //               value) so that only f[Q] and ~25 scalars stay live.
@@ -411,7 +453,7 @@ __device__ __forceinline__ void collide_kbc(T (&f)[S::Q][VEC], T beta, T inv_bet
   T rho, j[3], u[3];
   moments<T, S, LAYOUT, VEC, k>(f, rho, j);
   u[0] = j[0] / rho; u[1] = j[1] / rho; u[2] = j[2] / rho;
-  T uxu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+  T uxu = square_norm<S, LAYOUT>(u);
   T feq[LEAN ? 1 : S::Q];
   if constexpr (!LEAN) {
     static_for<S::Q>([&](auto qc) {
@@ -685,7 +727,7 @@ __global__ void __launch_bounds__(kThreads) equilibrium_kernel(const T *__restri
   T u[3] = {T(0), T(0), T(0)};
 #pragma unroll
   for (int a = 0; a < S::D; ++a) u[M::memory(a)] = u_in[(long long)a * N + i];
-  const T uxu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+  const T uxu = square_norm<S, LAYOUT>(u);
   static_for<S::Q>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
     feq_out[(long long)q * N + i] = feq_q<T, S, LAYOUT, q>(rho, u, uxu);
@@ -731,8 +773,8 @@ __global__ void __launch_bounds__(kThreads) reduce_kernel(const T *__restrict__ 
     T rho, j[3];
     moments<T, S, LAYOUT, 1, 0>(g, rho, j);
     if constexpr (MODE == 0) {
-      const T ux = j[0] / rho, uy = j[1] / rho, uz = j[2] / rho;
-      acc += (double)(T(0.5) * (ux * ux + uy * uy + uz * uz));
+      const T uu[3] = {j[0] / rho, j[1] / rho, j[2] / rho};
+      acc += (double)(T(0.5) * square_norm<S, LAYOUT>(uu));
     } else if constexpr (MODE == 1) {
       acc += (double)rho;
     } else {

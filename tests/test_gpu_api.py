@@ -162,11 +162,10 @@ def test_taylor_green_with_reporter_batches(name, stencil, coll, dt, n):
     assert steps == list(range(0, n + 1, 10))
     ref = dict(zip(g["energy_steps"].tolist(), g["energy_pu"].tolist()))
     for i, _, e in out:
-        # north star: KE decay to 1e-6 relative -- met in fp64 (observed ~1e-12).  In fp32 the
-        # reference's OWN run drifts from its fp64 run by 1.1e-7 per step (golden
-        # tgv3d_d3q19_bgk_16_f32 vs _f64: -1.1e-6 at step 10, -1.25e-5 at step 100; SURVEY.md
-        # 8(d)), so fp32 parity is bounded by that drift, not by 1e-6.
-        rel = 1e-9 if dt == "f64" else 5e-7 + 2e-7 * i
+        # north star: KE decay to 1e-6 relative -- fp64 observed ~1e-12; fp32 observed ~1e-7 against
+        # the reference's fp32 series (its fp32-specific rounding of the cs^2 divisors is
+        # reproduced in the kernel, see kernels.hpp div_cs)
+        rel = 1e-9 if dt == "f64" else 1e-6
         assert e == pytest.approx(ref[i], rel=rel)
     atol = (1e-12 if dt == "f64" else 1e-5) * float(np.abs(g[f"f{n}"]).max())
     np.testing.assert_allclose(flow.f.cpu().numpy(), g[f"f{n}"], rtol=0, atol=atol)
@@ -394,8 +393,10 @@ def test_full_size_cfg3_slab_equals_single_domain():
 
 def test_long_run_energy_decay_fp32_tracks_fp64():
     """1000 steps of TGV3D D3Q19 at 64^3 on the HIP engine: the fp32 kinetic-energy series decays
-    monotonically and stays within 1e-4 of the fp64 series (the reference's own fp32-vs-fp64 gap
-    is 1.3e-5 per 100 steps)."""
+    monotonically and stays within 3e-4 of the fp64 series.  The gap is the reference's own: its
+    fp32 path divides by cs^2 constants rounded to fp32 (3e-8 too large), which costs 1.1e-7 of
+    kinetic energy per step (1.25e-5 per 100 steps); the kernel reproduces that
+    arithmetic exactly in order to track the reference's fp32 results."""
     series = {}
     for dt in ("f64", "f32"):
         flow = lt.TaylorGreenVortex(gpu(dt), [64] * 3, 1600, 0.1, lt.D3Q19())
@@ -407,7 +408,9 @@ def test_long_run_energy_decay_fp32_tracks_fp64():
         series[dt] = np.array([row[2] for row in out])
         assert torch.isfinite(flow.f).all()
     assert len(series["f64"]) == 11 and (np.diff(series["f64"]) < 0).all() and (np.diff(series["f32"]) < 0).all()
-    np.testing.assert_allclose(series["f32"], series["f64"], rtol=1e-4)
+    np.testing.assert_allclose(series["f32"], series["f64"], rtol=3e-4)
+    drift = (series["f32"][-1] - series["f64"][-1]) / series["f64"][-1]
+    assert -2.5e-4 < drift < -0.5e-4          # the reference-inherent loss, about -1.2e-4 here
 
 
 def test_integration_md_ctypes_stub_steps_a_simulation():
