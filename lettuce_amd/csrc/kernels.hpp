@@ -270,30 +270,48 @@ __device__ __forceinline__ void add_momentum(T (&j)[3], T v) {
     else if constexpr (e < 0) j[m] -= v;
   });
 }
-// e_q . u
+// e_q . u, accumulated over the logical axes x, y, z from zero (the GEMM order of the reference's
+// tensordot(e, u); matters for the three-component velocities of D3Q15 / D3Q27)
 template <class S, int LAYOUT, int q, typename T>
 __device__ __forceinline__ T dot_e(const T (&u)[3]) {
   using M = MemMap<S, LAYOUT>;
   T r = T(0);
-  static_for<3>([&](auto mc) {
-    constexpr int m = decltype(mc)::value;
-    constexpr int e = M::e(q, m);
-    if constexpr (e > 0) r += u[m];
-    else if constexpr (e < 0) r -= u[m];
+  static_for<S::D>([&](auto ac) {
+    constexpr int a = decltype(ac)::value;
+    constexpr int e = S::E[q][a];
+    if constexpr (e > 0) r += u[M::memory(a)];
+    else if constexpr (e < 0) r -= u[M::memory(a)];
   });
   return r;
 }
 
+// Sum over q in the order of torch.sum(f, dim=0) on the CPU (ATen cascade_sum: the first 16
+// terms are accumulated from zero, then the remaining terms from zero, then the two partial sums
+// are added) -- bit-identical to the reference's Flow.rho() for every lattice; sum_q e_q f_q is a
+// GEMM in the reference and accumulates sequentially in q, as add_momentum does.
+template <int Q, typename T>
+struct CascadeSum {
+  T head = T(0), tail = T(0);
+  template <int q>
+  __device__ __forceinline__ void add(T v) {
+    if constexpr (q < 16) head += v; else tail += v;
+  }
+  __device__ __forceinline__ T result() const {
+    if constexpr (Q > 16) return tail + head; else return head;
+  }
+};
+
 template <typename T, class S, int LAYOUT, int VEC, int k>
 __device__ __forceinline__ void moments(const T (&f)[S::Q][VEC], T &rho, T (&j)[3]) {
-  rho = T(0);
+  CascadeSum<S::Q, T> mass;
   j[0] = j[1] = j[2] = T(0);
   static_for<S::Q>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
     const T v = f[q][k];
-    rho += v;
+    mass.template add<q>(v);
     add_momentum<S, LAYOUT, q>(j, v);
   });
+  rho = mass.result();
 }
 
 // value barrier: the optimiser may not assume anything about x afterwards
@@ -334,8 +352,15 @@ __device__ __forceinline__ float div_cs(float x) {
 }
 template <int WHICH>
 __device__ __forceinline__ double div_cs(double x) {
-  constexpr double d = WHICH == 0 ? 2.0 * kCs2 : kCs2;
-  return x * (1.0 / d);
+  // same construction in fp64: 1 / D = hi + lo for D = 2 cs^2 = 0x1.5555555555557p-1 and
+  // D = cs^2 = 0x1.5555555555557p-2 (exact rationals evaluated offline; checked against IEEE
+  // division on 2e4 random arguments without a mismatch)
+  constexpr double hi = WHICH == 0 ? 0x1.7fffffffffffep+0 : 0x1.7fffffffffffep+1;
+  constexpr double lo = WHICH == 0 ? 0x1.0000000000013p-55 : 0x1.0000000000013p-54;
+  static_assert(2.0 * kCs2 == 0x1.5555555555557p-1 && kCs2 == 0x1.5555555555557p-2, "cs^2 constants");
+  const double p = launder(x * hi);
+  const double err = fma(x, hi, -p);
+  return p + fma(x, lo, err);
 }
 
 // QuadraticEquilibrium (lettuce/ext/_equilibrium/quadratic_equilibrium.py:15-24), u along
@@ -469,16 +494,17 @@ __device__ __forceinline__ void collide_kbc(T (&f)[S::Q][VEC], T beta, T inv_bet
   const KbcS<T, S> sf = kbc_s<T, S>([&](auto qc) { return f[decltype(qc)::value][k]; });
   const KbcS<T, S> se = kbc_s<T, S>(eq);
   if constexpr (LEAN) { rho = launder(rho); u[0] = launder(u[0]); u[1] = launder(u[1]); u[2] = launder(u[2]); uxu = launder(uxu); }
-  T sum_s = T(0), sum_h = T(0);
+  CascadeSum<S::Q, T> acc_s, acc_h;            // flow.rho(...) = torch.sum over q
   static_for<S::Q>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
     const T fe = eq(qc);
     const T ds = sf.template get<q>() - se.template get<q>();
     const T dh = f[q][k] - fe - ds;
     const T t = kbc_ratio(dh, fe);
-    sum_s += ds * t;
-    sum_h += dh * t;
+    acc_s.template add<q>(ds * t);
+    acc_h.template add<q>(dh * t);
   });
+  const T sum_s = acc_s.result(), sum_h = acc_h.result();
   T gamma = inv_beta - (T(2) - inv_beta) * sum_s / sum_h;
   if (gamma < T(1e-15)) gamma = T(2);
   if (gamma != gamma) gamma = T(2);
