@@ -716,6 +716,14 @@ __global__ void __launch_bounds__(kThreads) lbm_kernel(const KParams<T> p) {
   lbm_body<T, S, LAYOUT, COLL, STREAM, COLLIDE, MASKED, VEC, SHIFT, TUNE, PACK>(p);
 }
 
+// same kernel with the register allocator told to fit 4 waves per SIMD (<= 128 VGPRs): the masked
+// D3Q27-KBC kernel sits at 131 VGPRs otherwise and loses a wave per SIMD (cfg4: 0.735 -> ms below)
+template <typename T, class S, int LAYOUT, int COLL, bool STREAM, bool COLLIDE, bool MASKED,
+          int VEC, int SHIFT, int TUNE = 0, bool PACK = false>
+__global__ void __launch_bounds__(kThreads, 4) lbm_kernel_occ4(const KParams<T> p) {
+  lbm_body<T, S, LAYOUT, COLL, STREAM, COLLIDE, MASKED, VEC, SHIFT, TUNE, PACK>(p);
+}
+
 // ---- auxiliary kernels --------------------------------------------------------------------
 // rho [N], u [d][N] (logical axis order) from f  -- Flow.rho / Flow.u
 template <typename T, class S, int LAYOUT>
