@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--cpu-baseline-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="slab path: exchange without overlap")
+    ap.add_argument("--transport", choices=["auto", "rccl", "window"], default="auto",
+                    help="slab path: ghost-plane transport (lettuce_amd/_slab.py); auto = run the "
+                         "warm-up with both, require bit-identical populations, keep the faster")
     ap.add_argument("--slab", action="store_true",
                     help="use the z-slab driver (and an RCCL process group) even with one GPU: "
                          "rehearsal of the N > 1 code path")
@@ -175,15 +178,61 @@ def main():
         else:
             global_res = [n, n, n * world]
         slab = lt.ZSlab(global_res)
-        flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 1600, 0.1, lt.D3Q19(), slab=slab)
-        sim = lt.SlabSimulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
-                                overlap=not args.no_overlap)
+
+        def build(transport):
+            flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 1600, 0.1, lt.D3Q19(), slab=slab)
+            return lt.SlabSimulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
+                                     overlap=not args.no_overlap, transport=transport)
+
+        def all_ranks(flag: bool) -> bool:
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
+        # candidates: the RCCL transport always; the one-sided window transport unless excluded.
+        # Each does 3 + W warm-up steps from the same initial state (the W timed, max over ranks); the
+        # window transport is only eligible when its populations are bit-identical to RCCL's.
+        wanted = ["rccl", "window"] if args.transport == "auto" else [args.transport]
+        sims, probe = {}, {}
+        for name in wanted:
+            try:
+                sims[name] = build(name)
+                ok = True
+            except Exception as exc:            # e.g. symmetric memory unavailable on this node
+                ok = False
+                probe[name] = f"unavailable: {type(exc).__name__}: {str(exc)[:120]}"
+            if not all_ranks(ok):
+                sims.pop(name, None)
+                probe.setdefault(name, "unavailable on another rank")
+        if not sims:
+            raise SystemExit(f"no usable slab transport: {probe}")
+        for name, cand in sims.items():
+            cand(3)                             # connection set-up, first launches: not timed
+            barrier()
+            t0 = time.perf_counter()
+            cand(max(args.warmup, 1))
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            probe[name] = round(float(t.item()) / max(args.warmup, 1) * 1e3, 5)
+        check = None
+        if len(sims) == 2:
+            same = all_ranks(torch.equal(sims["rccl"].f[:, 1:-1], sims["window"].f[:, 1:-1]))
+            check = "bit-identical to rccl" if same else "MISMATCH: window transport rejected"
+            if not same:
+                del sims["window"]
+        chosen = min(sims, key=lambda k: probe[k])
+        sim = sims.pop(chosen)
+        sims.clear()
+        cand = None
+        torch.cuda.empty_cache()
         nodes_per_rank = global_res[0] * global_res[1] * slab.nz_local
         kernel = sim.engine.kernel_name()
-        sim(args.warmup)
         step = sim
-        parallelism = f"z-slab x{world}, RCCL send/recv ghost planes" + (
-            "" if not args.no_overlap else " (no overlap)")
+        how = ("RCCL send/recv ghost planes" if chosen == "rccl"
+               else "one-sided ghost-plane stores into peer windows (xGMI peer access)")
+        parallelism = f"z-slab x{world}, {how}" + ("" if not args.no_overlap else " (no overlap)")
+        transport_info = {"chosen": chosen, "warmup_ms_per_step": probe, "check": check}
 
     barrier()
     t0 = time.perf_counter()
@@ -234,6 +283,8 @@ def main():
                        "passes_per_batch": "1 collide + (K-1) fused stream-collide + 1 stream"},
             "roofline": roofline,
         }
+        if distributed:
+            line["config"]["transport"] = transport_info
         if not distributed and not args.no_cpu_baseline:
             del sim, flow
             torch.cuda.empty_cache()

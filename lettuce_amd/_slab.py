@@ -6,9 +6,19 @@ to its two z-neighbours only.
 
 Layout.  A rank stores its slab as ``[q][nz_local + 2][ny][nx]`` (x fastest, z slowest --
 ``LT_LAYOUT_SLAB`` of include/lettuce_hip.h) with one ghost plane below and above.  With z
-slowest a ghost plane of one population is a single contiguous ``ny*nx`` block, so the halo
-exchange sends straight out of and receives straight into the population buffers: no pack or
-unpack kernels and no staging copies.
+slowest a ghost plane of one population is a single contiguous ``ny*nx`` block; the crossing
+populations of a boundary plane are gathered into one message per direction by the same launch
+that computes the plane.
+
+Transports (``transport=``):
+  "rccl"    batched isend/irecv through the process group (RCCL point-to-point over xGMI; gloo in
+            the CPU tests).  The default.
+  "window"  one-sided: every rank exposes a receive window (torch symmetric memory: peer-mapped
+            device memory + signal pads); the boundary-plane launch stores the crossing
+            populations straight into the neighbours' windows over xGMI, a signal follows, the
+            receiver waits for the signal and unpacks.  No copy kernel competes with the interior
+            launch for HBM.  Two window parities make the reuse safe without a barrier (see
+            ``_PeerWindow``).
 
 Schedule of one fused step (pull scheme, state = post-collision populations f*):
   communication stream (high priority)          compute stream
@@ -85,6 +95,51 @@ def _crossing_sets(stencil):
     return up, down
 
 
+class _PeerWindow:
+    """Receive windows for the one-sided ghost-plane transfer.
+
+    ``local[p, 0]`` receives the e_z = +1 populations from the lower neighbour (they fill my lower
+    ghost plane), ``local[p, 1]`` the e_z = -1 populations from the upper neighbour; p is the
+    parity of the exchange counter.  A neighbour can only write parity p again two exchanges
+    later, i.e. after it has waited for my signal of the exchange in between, which I raise after
+    (in stream order) my unpack of parity p: no barrier is needed.  Signals: channel 0 travels
+    upwards with the +z data, channel 1 downwards with the -z data.
+    """
+
+    WAIT_MS = 20000       # a lost signal traps instead of spinning for ever
+
+    def __init__(self, shape, dtype, device, slab: ZSlab, group):
+        import torch.distributed._symmetric_memory as symm
+        self.slab = slab
+        full = (2, 2) + tuple(shape)
+        with torch.cuda.device(device):
+            self.buf = symm.empty(full, dtype=dtype, device=device)
+            self.buf.zero_()
+            self.handle = symm.rendezvous(self.buf, group if group is not None else dist.group.WORLD)
+            self.local = self.buf
+            self.at_prev = self.handle.get_buffer(slab.prev, full, dtype, 0)
+            self.at_next = self.handle.get_buffer(slab.next, full, dtype, 0)
+            torch.cuda.synchronize(device)
+            self.handle.barrier(2, self.WAIT_MS)
+        self.count = 0
+
+    def targets(self):
+        """(where my -z message goes, where my +z message goes) for the coming exchange"""
+        p = self.count & 1
+        return self.at_prev[p, 1], self.at_next[p, 0]
+
+    def signal_and_wait(self):
+        """after the stores of this exchange (same stream): tell both neighbours, wait for both;
+        returns (message from above, message from below)"""
+        p, s, h = self.count & 1, self.slab, self.handle
+        h.put_signal(s.prev, 1, self.WAIT_MS)
+        h.put_signal(s.next, 0, self.WAIT_MS)
+        h.wait_signal(s.next, 1, self.WAIT_MS)
+        h.wait_signal(s.prev, 0, self.WAIT_MS)
+        self.count += 1
+        return self.local[p, 1], self.local[p, 0]
+
+
 class SlabSimulation:
     """Time-step driver of one rank's slab.
 
@@ -97,7 +152,7 @@ class SlabSimulation:
     """
 
     def __init__(self, flow, collision, slab: ZSlab, reporter=None, engine=None, group=None,
-                 overlap: bool = True, comm_priority: int = -1):
+                 overlap: bool = True, comm_priority: int = -1, transport: str = "rccl"):
         if list(flow.resolution) != slab.extended_resolution:
             raise LettuceException(f"flow resolution {flow.resolution} != extended slab "
                                    f"{slab.extended_resolution}")
@@ -159,6 +214,15 @@ class SlabSimulation:
                            and dist.is_initialized())
         self._host_transport = ((slab.world_size > 1 or self._force_p2p)
                                 and dist.get_backend(group) != "nccl")
+        if transport not in ("rccl", "window"):
+            raise LettuceException(f"unknown slab transport '{transport}'")
+        self.transport = transport
+        self._window = None
+        if transport == "window":
+            if self.context.device.type != "cuda" or not (dist.is_available() and dist.is_initialized()):
+                raise LettuceException("the window transport needs device memory and an initialised "
+                                       "process group")
+            self._window = _PeerWindow(shape, self.f.dtype, self.f.device, slab, group)
 
     # ---- views ---------------------------------------------------------------------------------
     def local_f(self) -> torch.Tensor:
@@ -200,6 +264,17 @@ class SlabSimulation:
         packed message per direction.  Returns a callable that completes the exchange (waits
         for the transfers and unpacks)."""
         nzl, s = self.nzl, self.slab
+        if self._window is not None:
+            if not packed:
+                to_prev, to_next = self._window.targets()
+                self._pack(buf, 1, -1, to_prev)
+                self._pack(buf, nzl, +1, to_next)
+            from_above, from_below = self._window.signal_and_wait()
+
+            def finish_window():
+                self._unpack(buf, nzl + 1, -1, from_above)
+                self._unpack(buf, 0, +1, from_below)
+            return finish_window
         if not packed:
             self._pack(buf, 1, -1, self._send_down)
             self._pack(buf, nzl, +1, self._send_up)
@@ -231,8 +306,9 @@ class SlabSimulation:
         """Stream-collide planes 1 and nz_local; returns True when the launch also packed the
         crossing populations into the send buffers."""
         if hasattr(self.engine, "stream_collide_plane_pair_packed"):
-            self.engine.stream_collide_plane_pair_packed(cur, nxt, tau, 1, self.nzl,
-                                                         self._send_down, self._send_up)
+            down, up = ((self._send_down, self._send_up) if self._window is None
+                        else self._window.targets())
+            self.engine.stream_collide_plane_pair_packed(cur, nxt, tau, 1, self.nzl, down, up)
             return True
         self.engine.stream_collide_planes(cur, nxt, tau, 1, 2)
         if self.nzl > 1:

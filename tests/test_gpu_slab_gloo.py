@@ -81,6 +81,39 @@ def test_rccl_point_to_point_path_with_self_exchange(tmp_path):
     np.testing.assert_allclose(got["f1"], ref.f.numpy(), rtol=0, atol=1e-5 * float(np.abs(ref.f.numpy()).max()))
 
 
+def _window_worker(rank, port, res, steps, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    import lettuce_amd as lt
+    ctx = lt.Context("cuda:0", torch.float64, use_native=True)
+    slab = lt.ZSlab(res)
+    flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 400, 0.1, lt.D3Q19(), slab=slab)
+    sim = lt.SlabSimulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
+                            transport="window")
+    assert sim._window is not None
+    sim(3)              # odd and even batch lengths: the window parity runs through both values
+    sim(steps - 3)
+    np.savez(os.path.join(out_dir, "out.npz"), f1=sim.gather_f().cpu().numpy(), ke=sim.kinetic_energy_pu(),
+             exchanges=sim._window.count)
+    dist.destroy_process_group()
+
+
+def test_window_transport_with_self_exchange(tmp_path):
+    """The one-sided transport (stores into the neighbour's receive window + signal pads, torch
+    symmetric memory) on one GPU: the single rank is its own lower and upper neighbour, so the
+    boundary-plane launch stores into its own window through the peer mapping."""
+    from oracle import lettuce_oracle as orc
+    res, steps = [64, 32, 16], 9
+    mp.spawn(_window_worker, args=(29900 + os.getpid() % 1000, res, steps, str(tmp_path)), nprocs=1, join=True)
+    got = np.load(tmp_path / "out.npz")
+    assert int(got["exchanges"]) == steps      # one exchange per step (1 after collide + n-1 fused, per batch)
+    ref = orc.taylor_green(res, 400, 0.1, "D3Q19", torch.float64)
+    ref.step(steps)
+    np.testing.assert_allclose(got["f1"], ref.f.numpy(), rtol=0, atol=1e-13)
+
+
 def _obstacle_worker(rank, world, port, name, steps, dtype_name, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
