@@ -27,10 +27,6 @@
 
 #include "lattice.hpp"
 
-#ifndef LT_KBC_LEAN
-#define LT_KBC_LEAN false
-#endif
-
 namespace lt {
 
 constexpr int kThreads = 256;
@@ -314,6 +310,9 @@ __device__ __forceinline__ void moments(const T (&f)[S::Q][VEC], T &rho, T (&j)[
   rho = mass.result();
 }
 
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 // value barrier: the optimiser may not assume anything about x afterwards
 __device__ __forceinline__ float launder(float x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ double launder(double x) { asm volatile("" : "+v"(x)); return x; }
@@ -334,33 +333,18 @@ __device__ __forceinline__ T square_norm(const T (&u)[3]) {
 // x / D for the constants D = 2 cs^2 and cs^2 of the equilibrium.  The reference divides the fp32
 // field by the python double cast to fp32 (D_f = 0.66666669 / 0.33333334, 3e-8 above 2/3 and 1/3);
 // that systematic 3e-8 is what makes its fp32 kinetic energy drift by -1.1e-7 per step against its
-// fp64 run.  To track the reference's fp32 path (not just fp64 truth) the same quotient is formed:
-// x / D_f = x * (hi + lo) with hi + lo = 1 / D_f to double precision, evaluated in double-float
-// arithmetic (the rounding error of x * hi is recovered with an FMA): four instructions instead of
-// a ~10-instruction IEEE division, and the same correctly rounded quotient in all but rare ties.
-template <int WHICH>   // 0: D = 2 cs^2, 1: D = cs^2
-__device__ __forceinline__ float div_cs(float x) {
-  constexpr double d = WHICH == 0 ? 2.0 * kCs2 : kCs2;
-  constexpr double inv = 1.0 / (double)(float)d;
-  constexpr float hi = (float)inv;
-  constexpr float lo = (float)(inv - (double)hi);
-  // the rounded product is hidden from the optimiser: hipcc otherwise re-fuses the final sum with
-  // the multiplication (p + c -> fma(x, hi, c)) and the recovered rounding error counts twice
-  const float p = launder(x * hi);
-  const float err = fmaf(x, hi, -p);
-  return p + fmaf(x, lo, err);
-}
-template <int WHICH>
-__device__ __forceinline__ double div_cs(double x) {
-  // same construction in fp64: 1 / D = hi + lo for D = 2 cs^2 = 0x1.5555555555557p-1 and
-  // D = cs^2 = 0x1.5555555555557p-2 (exact rationals evaluated offline; checked against IEEE
-  // division on 2e4 random arguments without a mismatch)
-  constexpr double hi = WHICH == 0 ? 0x1.7fffffffffffep+0 : 0x1.7fffffffffffep+1;
-  constexpr double lo = WHICH == 0 ? 0x1.0000000000013p-55 : 0x1.0000000000013p-54;
-  static_assert(2.0 * kCs2 == 0x1.5555555555557p-1 && kCs2 == 0x1.5555555555557p-2, "cs^2 constants");
-  const double p = launder(x * hi);
-  const double err = fma(x, hi, -p);
-  return p + fma(x, lo, err);
+// fp64 run.  To track the reference's fp32 path (not just fp64 truth) the same IEEE quotient is
+// formed, in three instructions instead of the ~10 of a division: q = RN(x r) with r = RN(1 / D),
+// the exact remainder x - q D by FMA, one correction step (Markstein).  Equal to x / D for every
+// fp32 x with |x / D| >= 1e-30 (exhaustive, tests/aux/exact_division_check.c) and in 6.4e9 random
+// fp64 quotients.
+template <int WHICH, typename T>   // 0: D = 2 cs^2, 1: D = cs^2
+__device__ __forceinline__ T div_cs(T x) {
+  constexpr T d = (T)(WHICH == 0 ? 2.0 * kCs2 : kCs2);
+  constexpr T r = (T)(1.0 / (double)d);
+  const T q = x * r;
+  const T rem = fma_t(-q, d, x);
+  return fma_t(rem, r, q);
 }
 
 // QuadraticEquilibrium (lettuce/ext/_equilibrium/quadratic_equilibrium.py:15-24), u along
@@ -377,6 +361,39 @@ __device__ __forceinline__ T feq_q(T rho, const T (&u)[3], T uxu) {
   return T(S::W[q]) * (rho * (a + T(0.5) * (b * b) + T(1)));
 }
 
+// the same for population q and its opposite o (q < o) together: e_o = -e_q, so e_o.u, 2 e_o.u
+// and (e_o.u) / cs^2 are the exact negatives and the quadratic term is shared -- the two values
+// are bit for bit what feq_q<q> and feq_q<o> return, for a third less arithmetic
+template <typename T, class S, int LAYOUT, int q>
+__device__ __forceinline__ void feq_pair(T rho, const T (&u)[3], T uxu, T &fq, T &fo) {
+#pragma clang fp contract(off)
+  const T exu = dot_e<S, LAYOUT, q>(u);
+  const T two = T(2) * exu;
+  const T b = div_cs<1>(exu);
+  const T h = T(0.5) * (b * b);
+  const T aq = div_cs<0>(two - uxu);
+  const T ao = div_cs<0>(-two - uxu);
+  fq = T(S::W[q]) * (rho * (aq + h + T(1)));
+  fo = T(S::W[q]) * (rho * (ao + h + T(1)));
+}
+
+// fn(q, feq_q) for every q (opposite pairs back to back, not in index order)
+template <typename T, class S, int LAYOUT, class F>
+__device__ __forceinline__ void for_each_feq(T rho, const T (&u)[3], T uxu, F &&fn) {
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int o = S::OPP[q];
+    if constexpr (q == o) {
+      fn(qc, feq_q<T, S, LAYOUT, q>(rho, u, uxu));
+    } else if constexpr (q < o) {
+      T a, b;
+      feq_pair<T, S, LAYOUT, q>(rho, u, uxu, a, b);
+      fn(qc, a);
+      fn(std::integral_constant<int, o>{}, b);
+    }
+  });
+}
+
 // ---- collisions ---------------------------------------------------------------------------
 template <typename T, class S, int LAYOUT, int VEC, int k>
 __device__ __forceinline__ void collide_bgk(T (&f)[S::Q][VEC], T tau_inv) {
@@ -384,78 +401,86 @@ __device__ __forceinline__ void collide_bgk(T (&f)[S::Q][VEC], T tau_inv) {
   moments<T, S, LAYOUT, VEC, k>(f, rho, j);
   u[0] = j[0] / rho; u[1] = j[1] / rho; u[2] = j[2] / rho;
   const T uxu = square_norm<S, LAYOUT>(u);
-  static_for<S::Q>([&](auto qc) {
+  for_each_feq<T, S, LAYOUT>(rho, u, uxu, [&](auto qc, T feq) {
 #pragma clang fp contract(off)
     constexpr int q = decltype(qc)::value;
-    const T feq = feq_q<T, S, LAYOUT, q>(rho, u, uxu);
     f[q][k] = f[q][k] - tau_inv * (f[q][k] - feq);
   });
 }
 
-// the KBC "s" vector from the second moments of a population set g
-// (lettuce/ext/_collision/kbc_collision.py:25-39 moments, :44-94 s_i)
+// KBC.  The reference forms s(f) and s(feq) from the second moments m/rho of f and of feq
+// (lettuce/ext/_collision/kbc_collision.py:25-39 moments, :44-94 s_i), each s_i being rho times a
+// linear combination of the normalised moments -- i.e. a linear function of the populations -- and
+// then ds = s(f) - s(feq).  Here ds is evaluated as s(f - feq) from the raw second moments of
+// x = f - feq: no division by rho and re-multiplication, one moment pass instead of two, and the
+// opposite pairs (equal e_a e_b) are summed first.  Same value up to rounding; KBC is compared with
+// the reference at rounding level, not bit for bit.
 template <typename T, class S>
 struct KbcS {
   T s0, sa, sb, sc, pxy, pxz, pyz;   // 3-D: s0, s1(=s2), s3(=s4), s5(=s6), s15, s11, s7
   template <int q>
-  __device__ __forceinline__ T get() const {
+  static constexpr int sign() {       // get<q>() == sign * component, 0: this s_q is zero
+    if constexpr (S::D == 3) return q >= 19 ? 0 : ((q >= 9 && q <= 10) || (q >= 13 && q <= 14) || q >= 17) ? -1 : 1;
+    else return (q == 6 || q == 8) ? -1 : 1;
+  }
+  template <int q>
+  __device__ __forceinline__ T magnitude() const {
     if constexpr (S::D == 3) {
       if constexpr (q == 0) return s0;
       else if constexpr (q <= 2) return sa;
       else if constexpr (q <= 4) return sb;
       else if constexpr (q <= 6) return sc;
-      else if constexpr (q <= 8) return pyz;
-      else if constexpr (q <= 10) return -pyz;
-      else if constexpr (q <= 12) return pxz;
-      else if constexpr (q <= 14) return -pxz;
-      else if constexpr (q <= 16) return pxy;
-      else if constexpr (q <= 18) return -pxy;
+      else if constexpr (q <= 10) return pyz;
+      else if constexpr (q <= 14) return pxz;
+      else if constexpr (q <= 18) return pxy;
       else return T(0);
     } else {
       if constexpr (q == 0) return s0;
       else if constexpr (q == 1 || q == 3) return sa;
       else if constexpr (q == 2 || q == 4) return sb;
-      else if constexpr (q == 5 || q == 7) return pxy;
-      else return -pxy;
+      else return pxy;
     }
+  }
+  __device__ __forceinline__ KbcS scaled(T c) const {
+    return KbcS{c * s0, c * sa, c * sb, c * sc, c * pxy, c * pxz, c * pyz};
   }
 };
 
+// s(g) for a population set given as g(q), from raw second moments (logical axes x, y, z)
 template <typename T, class S, class G>
 __device__ __forceinline__ KbcS<T, S> kbc_s(const G &g) {
-  // g(q) returns population q; logical axes (KBC is written in x,y,z)
-  T rho = T(0), xx = T(0), yy = T(0), zz = T(0), xy = T(0), xz = T(0), yz = T(0);
+  T xx = T(0), yy = T(0), zz = T(0), xy = T(0), xz = T(0), yz = T(0);
   static_for<S::Q>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
-    constexpr int ex = S::E[q][0], ey = S::E[q][1], ez = S::E[q][2];
-    const T v = g(qc);
-    rho += v;
-    if constexpr (ex != 0) xx += v;
-    if constexpr (ey != 0) yy += v;
-    if constexpr (ez != 0) zz += v;
-    if constexpr (ex * ey > 0) xy += v; else if constexpr (ex * ey < 0) xy -= v;
-    if constexpr (ex * ez > 0) xz += v; else if constexpr (ex * ez < 0) xz -= v;
-    if constexpr (ey * ez > 0) yz += v; else if constexpr (ey * ez < 0) yz -= v;
+    constexpr int o = S::OPP[q];
+    if constexpr (q < o) {
+      constexpr int ex = S::E[q][0], ey = S::E[q][1], ez = S::E[q][2];
+      const T v = g(qc) + g(std::integral_constant<int, o>{});
+      if constexpr (ex != 0) xx += v;
+      if constexpr (ey != 0) yy += v;
+      if constexpr (ez != 0) zz += v;
+      if constexpr (ex * ey > 0) xy += v; else if constexpr (ex * ey < 0) xy -= v;
+      if constexpr (ex * ez > 0) xz += v; else if constexpr (ex * ez < 0) xz -= v;
+      if constexpr (ey * ez > 0) yz += v; else if constexpr (ey * ez < 0) yz -= v;
+    }
   });
-  xx /= rho; yy /= rho; xy /= rho;
   KbcS<T, S> s;
   if constexpr (S::D == 3) {
-    zz /= rho; xz /= rho; yz /= rho;
     const T Tr = xx + yy + zz, nxz = xx - zz, nyz = yy - zz;
-    s.s0 = rho * -Tr;
-    s.sa = T(1. / 6.) * rho * (T(2) * nxz - nyz + Tr);
-    s.sb = T(1. / 6.) * rho * (T(2) * nyz - nxz + Tr);
-    s.sc = T(1. / 6.) * rho * (-nxz - nyz + Tr);
-    s.pyz = T(0.25) * rho * yz;
-    s.pxz = T(0.25) * rho * xz;
-    s.pxy = T(0.25) * rho * xy;
+    s.s0 = -Tr;
+    s.sa = T(1. / 6.) * (T(2) * nxz - nyz + Tr);
+    s.sb = T(1. / 6.) * (T(2) * nyz - nxz + Tr);
+    s.sc = T(1. / 6.) * (-nxz - nyz + Tr);
+    s.pyz = T(0.25) * yz;
+    s.pxz = T(0.25) * xz;
+    s.pxy = T(0.25) * xy;
   } else {
     const T Tr = xx + yy, n = xx - yy;
-    s.s0 = rho * -Tr;
-    s.sa = T(0.5) * rho * (T(0.5) * (Tr + n));
-    s.sb = T(0.5) * rho * (T(0.5) * (Tr - n));
+    s.s0 = -Tr;
+    s.sa = T(0.5) * (T(0.5) * (Tr + n));
+    s.sb = T(0.5) * (T(0.5) * (Tr - n));
     s.sc = T(0);
-    s.pxy = T(0.25) * rho * xy;
+    s.pxy = T(0.25) * xy;
     s.pxz = s.pyz = T(0);
   }
   return s;
@@ -465,56 +490,50 @@ __device__ __forceinline__ KbcS<T, S> kbc_s(const G &g) {
 // (ds*dh/feq and dh*dh/feq, kbc_collision.py:150-151); here dh/feq is formed once and, in fp32,
 // with the hardware reciprocal (<= 1 ulp) instead of the ~10-instruction IEEE sequence: the sums
 // feed only gamma, whose own rounding noise (dh is a difference of nearly equal numbers) is three
-// orders of magnitude larger.  This takes D3Q27-KBC from ALU-bound to HBM-bound.
+// orders of magnitude larger.
 __device__ __forceinline__ float kbc_ratio(float x, float y) { return x * __builtin_amdgcn_rcpf(y); }
 __device__ __forceinline__ double kbc_ratio(double x, double y) { return x / y; }
 
-// LEAN = false: feq[Q] is evaluated once and kept (D3Q27 fp32: 139 VGPRs, 3 waves/SIMD).
-// LEAN = true:  feq_q is re-evaluated in each of the three passes over q (same expression, same
-//               value) so that only f[Q] and ~25 scalars stay live.
-template <typename T, class S, int LAYOUT, int VEC, int k, bool LEAN = LT_KBC_LEAN>
+// f' = f - beta (2 ds + gamma dh), dh = f - feq - ds (kbc_collision.py:130-158), evaluated as
+// f - (beta gamma) (f - feq) - (beta (2 - gamma)) ds with the seven distinct ds values scaled once.
+template <typename T, class S, int LAYOUT, int VEC, int k>
 __device__ __forceinline__ void collide_kbc(T (&f)[S::Q][VEC], T beta, T inv_beta) {
   static_assert(S::Q == 9 || S::Q == 27, "KBC exists for D2Q9 and D3Q27 only (kbc_collision.py:100-128)");
   T rho, j[3], u[3];
   moments<T, S, LAYOUT, VEC, k>(f, rho, j);
   u[0] = j[0] / rho; u[1] = j[1] / rho; u[2] = j[2] / rho;
-  T uxu = square_norm<S, LAYOUT>(u);
-  T feq[LEAN ? 1 : S::Q];
-  if constexpr (!LEAN) {
-    static_for<S::Q>([&](auto qc) {
-      constexpr int q = decltype(qc)::value;
-      feq[q] = feq_q<T, S, LAYOUT, q>(rho, u, uxu);
-    });
-  }
-  auto eq = [&](auto qc) -> T {
+  const T uxu = square_norm<S, LAYOUT>(u);
+  T feq[S::Q];
+  for_each_feq<T, S, LAYOUT>(rho, u, uxu, [&](auto qc, T v) { feq[decltype(qc)::value] = v; });
+  const KbcS<T, S> ds = kbc_s<T, S>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
-    if constexpr (LEAN) return feq_q<T, S, LAYOUT, q>(rho, u, uxu);
-    else return feq[q];
-  };
-  const KbcS<T, S> sf = kbc_s<T, S>([&](auto qc) { return f[decltype(qc)::value][k]; });
-  const KbcS<T, S> se = kbc_s<T, S>(eq);
-  if constexpr (LEAN) { rho = launder(rho); u[0] = launder(u[0]); u[1] = launder(u[1]); u[2] = launder(u[2]); uxu = launder(uxu); }
-  CascadeSum<S::Q, T> acc_s, acc_h;            // flow.rho(...) = torch.sum over q
+    return f[q][k] - feq[q];
+  });
+  CascadeSum<S::Q, T> acc_s, acc_h;
   static_for<S::Q>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
-    const T fe = eq(qc);
-    const T ds = sf.template get<q>() - se.template get<q>();
-    const T dh = f[q][k] - fe - ds;
-    const T t = kbc_ratio(dh, fe);
-    acc_s.template add<q>(ds * t);
+    constexpr int sg = KbcS<T, S>::template sign<q>();
+    const T x = f[q][k] - feq[q];
+    const T m = ds.template magnitude<q>();
+    const T dh = sg == 0 ? x : (sg > 0 ? x - m : x + m);
+    const T t = kbc_ratio(dh, feq[q]);
+    if constexpr (sg > 0) acc_s.template add<q>(m * t);
+    if constexpr (sg < 0) acc_s.template add<q>(-(m * t));
     acc_h.template add<q>(dh * t);
   });
   const T sum_s = acc_s.result(), sum_h = acc_h.result();
   T gamma = inv_beta - (T(2) - inv_beta) * sum_s / sum_h;
   if (gamma < T(1e-15)) gamma = T(2);
   if (gamma != gamma) gamma = T(2);
-  if constexpr (LEAN) { rho = launder(rho); u[0] = launder(u[0]); u[1] = launder(u[1]); u[2] = launder(u[2]); uxu = launder(uxu); }
+  const T bg = beta * gamma;
+  const KbcS<T, S> dsc = ds.scaled(beta * (T(2) - gamma));
   static_for<S::Q>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
-    const T fe = eq(qc);
-    const T ds = sf.template get<q>() - se.template get<q>();
-    const T dh = f[q][k] - fe - ds;
-    f[q][k] = f[q][k] - beta * (T(2) * ds + gamma * dh);
+    constexpr int sg = KbcS<T, S>::template sign<q>();
+    const T x = f[q][k] - feq[q];
+    const T y = f[q][k] - bg * x;
+    const T m = dsc.template magnitude<q>();
+    f[q][k] = sg == 0 ? y : (sg > 0 ? y - m : y + m);
   });
 }
 
@@ -762,9 +781,8 @@ __global__ void __launch_bounds__(kThreads) equilibrium_kernel(const T *__restri
 #pragma unroll
   for (int a = 0; a < S::D; ++a) u[M::memory(a)] = u_in[(long long)a * N + i];
   const T uxu = square_norm<S, LAYOUT>(u);
-  static_for<S::Q>([&](auto qc) {
-    constexpr int q = decltype(qc)::value;
-    feq_out[(long long)q * N + i] = feq_q<T, S, LAYOUT, q>(rho, u, uxu);
+  for_each_feq<T, S, LAYOUT>(rho, u, uxu, [&](auto qc, T v) {
+    feq_out[(long long)decltype(qc)::value * N + i] = v;
   });
 }
 
