@@ -227,6 +227,10 @@ int lt_plan_set_graph_mode(lt_plan *plan, int32_t mode);
  * wide != 0 switches the hot kernel (fused, BGK, no masks) to its 16-byte-per-lane A/B variant,
  * whose shift handling lt_plan_set_shift_policy selects. */
 int lt_plan_set_tuning(lt_plan *plan, int32_t cache_policy, int32_t wide);
+/* Workgroups resident per CU for the chip-filling launches (an unused dynamic-LDS allocation caps
+ * them): -1 = automatic (3, or 4 for fp32 KBC, once the populations stream from HBM and the launch
+ * fills the chip several times over; no cap otherwise), 0 = no cap, 2..8 = that many. */
+int lt_plan_set_residency(lt_plan *plan, int32_t workgroups_per_cu);
 
 #ifdef __cplusplus
 }

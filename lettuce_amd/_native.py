@@ -88,6 +88,7 @@ SYMBOLS = {
     "lt_plan_set_shift_policy": (ctypes.c_int, [_vp, _i32]),
     "lt_plan_set_graph_mode": (ctypes.c_int, [_vp, _i32]),
     "lt_plan_set_tuning": (ctypes.c_int, [_vp, _i32, _i32]),
+    "lt_plan_set_residency": (ctypes.c_int, [_vp, _i32]),
     "lt_probe_copy": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
 }
 
@@ -425,3 +426,7 @@ class Plan:
 
     def set_tuning(self, cache_policy: int = -1, wide: bool = False):
         self._check(self.lib.lt_plan_set_tuning(self._handle, int(cache_policy), int(bool(wide))))
+
+    def set_residency(self, workgroups_per_cu: int = -1):
+        """-1 automatic, 0 no cap, 2..8 workgroups resident per CU for the chip-filling launches"""
+        self._check(self.lib.lt_plan_set_residency(self._handle, int(workgroups_per_cu)))

@@ -76,6 +76,7 @@ struct lt_plan {
   int wide_ok;               // n0 divisible by the 16-byte vector width
   int shift;
   int tune = -1;             // cache policy: -1 = automatic
+  int residency = -1;        // workgroups per CU of the big launches: -1 = automatic, 0 = no cap
   int want_wide = 0;         // 16-byte accesses for the hot kernel (A/B experiments)
   // engine-owned device scratch
   unsigned char *node = nullptr;
@@ -90,7 +91,7 @@ struct lt_plan {
   hipStream_t gstream = nullptr;
   hipEvent_t gev_in = nullptr, gev_out = nullptr;
   hipGraphExec_t gexec = nullptr;
-  struct { void *a, *b; double tau; int masked, tune, wide, shift; } gkey = {};
+  struct { void *a, *b; double tau; int masked, tune, wide, shift, residency; } gkey = {};
 };
 
 namespace {
@@ -203,6 +204,24 @@ int resolve_tune(const lt_plan *p, int wide) {
   return bytes > (128ll << 20) ? 3 : 0;
 }
 
+// Fewer resident waves stream better: with 19-27 read and as many write streams per workgroup,
+// 3 workgroups per CU (3 waves per SIMD) instead of the 8 the registers allow ran 1-4 % faster on
+// MI355X (tools/occupancy_probe.py: D3Q19 fp32 -1.3..-2.7 %, D3Q27 fp32 -1..-4 %, D3Q19 fp64
+// -2..-4 %; 2 per CU is 15 % slower in fp32).  fp32 KBC, the one kernel with real arithmetic, gets 4.  The cap is an unused dynamic-LDS
+// allocation (160 KB per CU).  Only for launches that fill the chip several times over and stream
+// from HBM; small launches (boundary planes beside the interior launch, small grids) stay uncapped.
+int resolve_lds(const lt_plan *p, long long workgroups) {
+  int n = p->residency;
+  if (n < 0) {
+    const long long bytes = 2ll * p->unit.q * p->N * p->esize;
+    const bool kbc32 = p->desc.collision == LT_COLLISION_KBC && p->esize == 4;
+    n = (bytes > (128ll << 20) && workgroups >= 8192) ? (kbc32 ? 4 : 3) : 0;
+  }
+  if (n <= 0 || n >= 8) return 0;
+  const int per_wg = (160 * 1024 / n) & ~2047;   // the LDS allocator rounds up: stay below 160 KB / n
+  return per_wg > 65536 ? 65536 : per_wg;
+}
+
 int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long pb, long long pe,
          void *stream, long long stride = 1, void *pack_lo = nullptr, void *pack_hi = nullptr) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
@@ -232,6 +251,7 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.wide = (p->want_wide && hot && p->wide_ok && aligned) ? 1 : 0;
   a.shift = a.wide ? p->shift : 0;
   a.tune = resolve_tune(p, a.wide);
+  a.lds_bytes = resolve_lds(p, ((long long)a.planes * a.n1 * a.n0 + 255) / 256);
   a.stream = static_cast<hipStream_t>(stream);
   a.pack_lo = pack_lo; a.pack_hi = pack_hi;
   a.pack_lo_plane = (int)pb; a.pack_hi_plane = (int)(pb + stride * (a.planes - 1));
@@ -265,7 +285,7 @@ long long run_graph(lt_plan *p, void *cur, void *other, double tau, long long fu
       return -fail(LT_ERR_HIP, "cannot create the graph stream/events");
   }
   const bool same = p->gexec && p->gkey.a == cur && p->gkey.b == other && p->gkey.tau == tau &&
-                    p->gkey.masked == p->masked && p->gkey.tune == p->tune &&
+                    p->gkey.masked == p->masked && p->gkey.tune == p->tune && p->gkey.residency == p->residency &&
                     p->gkey.wide == p->want_wide && p->gkey.shift == p->shift;
   if (!same) {
     if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
@@ -284,7 +304,7 @@ long long run_graph(lt_plan *p, void *cur, void *other, double tau, long long fu
     const hipError_t ei = hipGraphInstantiate(&p->gexec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) { p->gexec = nullptr; return -fail(LT_ERR_HIP, "hipGraphInstantiate failed"); }
-    p->gkey = {cur, other, tau, p->masked, p->tune, p->want_wide, p->shift};
+    p->gkey = {cur, other, tau, p->masked, p->tune, p->want_wide, p->shift, p->residency};
   }
   const long long reps = fused / kGraphChunk;
   if (hipEventRecord(p->gev_in, user) != hipSuccess ||
@@ -601,6 +621,14 @@ int lt_plan_set_graph_mode(lt_plan *p, int32_t mode) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (mode < -1 || mode > 1) return fail(LT_ERR_INVALID, "graph mode %d", mode);
   p->graph_mode = mode;
+  return LT_OK;
+}
+
+int lt_plan_set_residency(lt_plan *p, int32_t workgroups_per_cu) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (workgroups_per_cu < -1 || workgroups_per_cu == 1 || workgroups_per_cu > 8)
+    return fail(LT_ERR_INVALID, "workgroups per CU %d (use -1, 0 or 2..8)", workgroups_per_cu);
+  p->residency = workgroups_per_cu;
   return LT_OK;
 }
 

@@ -21,6 +21,7 @@ struct StepArgs {
   const void *bt;        // BoundaryTable<T>* (device)
   int nb;
   int layout, coll, mode, masked, wide, shift, tune;
+  int lds_bytes;         // unused dynamic LDS per workgroup (residency cap), 0 = none
   void *pack_lo, *pack_hi;         // fused halo packing (slab boundary launch) or null
   int pack_lo_plane, pack_hi_plane;
   hipStream_t stream;

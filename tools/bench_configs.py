@@ -15,6 +15,18 @@ def timed(sim, warm, steps):
     sim._native.fused_events = None
     return dt, fused_ms
 
+def residency_ab(sim, steps=40):
+    """fused-kernel ms for a few residency caps, interleaved (RESIDENCY_AB=1)"""
+    if not os.environ.get("RESIDENCY_AB"):
+        return
+    out = {}
+    for r in range(3):
+        for cap in (0, 5, 4, 3, -1):
+            sim._native.plan.set_residency(cap)
+            out.setdefault(cap, []).append(timed(sim, 2, steps)[1])
+    sim._native.plan.set_residency(-1)
+    print(json.dumps({"residency_ab_ms": {k: round(sorted(v)[1], 4) for k, v in out.items()}}), flush=True)
+
 def report(name, flow, sim, dt, fused_ms, steps, bytes_per_node):
     n = 1
     for r in flow.resolution: n *= r
@@ -45,6 +57,7 @@ def main():
         sim = lt.Simulation(flow, collision, [])
         dt, ms = timed(sim, 10, 100)
         report(f"cfg4 Obstacle3D D3Q27 256^3 {coll.upper()} fp32, inlet+ABB outlet+sphere BB", flow, sim, dt, ms, 100, 217)
+        residency_ab(sim)
         u = flow.u()
         print(json.dumps({"finite": bool(torch.isfinite(flow.f).all()), "umax_lu": float(u.abs().max())}), flush=True)
         del sim, flow
@@ -55,5 +68,6 @@ def main():
         sim = lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])
         dt, ms = timed(sim, 10, 100)
         report("cfg5 per-GPU slab: periodic shear D3Q19 384x384x96 BGK fp64", flow, sim, dt, ms, 100, 304)
+        residency_ab(sim)
 
 main()
