@@ -306,3 +306,20 @@ def test_cli_benchmark_and_convergence_on_cpu(capsys):
     from lettuce_amd.cli import main
     assert main(["--no-cuda", "-p", "double", "benchmark", "-s", "3", "-r", "32", "-f", "taylor2D"]) == 0
     assert "MLUPS" in capsys.readouterr().out
+
+
+def test_three_instruction_division_by_the_cs2_constants_is_the_ieee_quotient(tmp_path):
+    """div_cs (kernels.hpp) replaces x / (2 cs^2) and x / cs^2 by a multiplication, an exact FMA
+    remainder and an FMA correction; the C check compares that sequence with the IEEE division
+    on every 61st fp32 bit pattern and on 4e7 random fp64 arguments (exhaustive fp32 run: stride 1)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    exe = tmp_path / "exact_division_check"
+    src = os.path.join(ROOT, "tests", "aux", "exact_division_check.c")
+    subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", src, "-o", str(exe), "-lm", "-lpthread"],
+                   check=True)
+    for args in (["f32", "61"], ["f64", "40000000"]):
+        out = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.strip() == "mismatches 0", (args, out.stdout, out.stderr)
