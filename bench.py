@@ -195,6 +195,19 @@ def main():
         wanted = ["rccl", "window"] if args.transport == "auto" else [args.transport]
         sims, probe = {}, {}
         for name in wanted:
+            if name == "window":
+                # preflight on every rank before the collective rendezvous inside build(): a rank
+                # that cannot allocate peer-mappable memory must not leave the others waiting
+                try:
+                    import torch.distributed._symmetric_memory as symm
+                    symm.empty(1024, dtype=torch.float32, device=device)
+                    ok = True
+                except Exception as exc:
+                    ok = False
+                    probe[name] = f"unavailable: {type(exc).__name__}: {str(exc)[:120]}"
+                if not all_ranks(ok):
+                    probe.setdefault(name, "unavailable on another rank")
+                    continue
             try:
                 sims[name] = build(name)
                 ok = True
