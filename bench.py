@@ -103,7 +103,9 @@ def traffic_from_profile(kernel_name):
     try:
         with open(path) as fh:
             table = json.load(fh)
-        want = kernel_name.lower().replace(" ", "")
+        # the engine's name and rocprofv3's differ only in case and in what follows the argument
+        # list ("void lt::...<...>(lt::KParams<float>)"): compare up to the closing bracket
+        want = kernel_name.lower().replace(" ", "").rstrip(">")
         for row in table.get("kernels", []):
             have = row.get("kernel", "").lower().replace(" ", "")
             if (row.get("workload") == "tgv3d_d3q19_bgk_f32_256" and want in have

@@ -436,3 +436,15 @@ def test_integration_md_ctypes_stub_steps_a_simulation():
     torch.cuda.synchronize()
     assert flow.i == 10
     np.testing.assert_allclose(flow.f.cpu().numpy(), g["f10"], rtol=0, atol=1e-5 * float(np.abs(g["f10"]).max()))
+
+
+def test_engine_kernel_name_matches_the_committed_traffic_profile():
+    """the name bench.py looks up in profiles/traffic.json is the one the 256^3 plan reports"""
+    import importlib.util
+    from conftest import ROOT
+    from lettuce_amd._native import Plan
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    plan = Plan("D3Q19", torch.float32, "bgk", [256, 256, 256], [], device=torch.device("cuda:0"))
+    assert bench.traffic_from_profile(plan.kernel_name()) is not None

@@ -323,3 +323,17 @@ def test_three_instruction_division_by_the_cs2_constants_is_the_ieee_quotient(tm
     for args in (["f32", "61"], ["f64", "40000000"]):
         out = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and out.stdout.strip() == "mismatches 0", (args, out.stdout, out.stderr)
+
+
+def test_bench_finds_the_committed_pmc_traffic_for_the_fused_kernel():
+    """bench.py fills roofline.traffic from profiles/traffic.json by kernel name; the name the
+    engine reports (lt_plan_kernel_name) and the one rocprofv3 prints differ in case and suffix."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    name = "lbm_kernel<float, lt::d3q19, 0, 1, true, true, false, 1, 0, 3, false>"
+    traffic = bench.traffic_from_profile(name)
+    assert traffic is not None
+    assert abs(traffic / (152 * 256 ** 3) - 1.0) < 0.02
+    assert bench.traffic_from_profile("lbm_kernel<float, lt::d3q19, 0, 1, true, true, false, 1, 0, 0, false>") is None
