@@ -2,6 +2,7 @@
 the reference's tests/native/* restated: the same flow is stepped by the CPU oracle and by
 ``Simulation`` on a native context, and the populations must agree."""
 import io
+import os
 from copy import copy
 
 import numpy as np

@@ -293,6 +293,36 @@ def test_full_size_properties_256cubed_fp32():
     assert torch.equal(r, f0)
 
 
+def test_more_than_2_to_the_31_elements_tiled_periodic_field_is_bit_identical():
+    """BASELINE cfg3's global size on one GPU (D3Q19 512^3 fp32: 2.55e9 elements per buffer, beyond
+    32-bit element offsets).  A field with period 256 in every direction must evolve exactly like
+    the 256^3 field it is tiled from: the per-node arithmetic is the same, only the addressing
+    differs."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs 40 GiB of free device memory")
+    n, steps = 256, 6
+    torch.manual_seed(1)
+    w = torch.tensor(orc.LATTICES["D3Q19"].w, dtype=torch.float32, device="cuda").reshape(19, 1, 1, 1)
+    f0 = w * (1 + 0.05 * torch.rand(19, n, n, n, device="cuda"))
+    small = plan_for("D3Q19", torch.float32, "bgk", [n] * 3)
+    ref, _ = small.run(f0.clone(), torch.empty_like(f0), 0.6, steps)
+    big = plan_for("D3Q19", torch.float32, "bgk", [2 * n] * 3)
+    a = f0.repeat(1, 2, 2, 2).contiguous()
+    assert a.numel() > 2 ** 31
+    b = torch.empty_like(a)
+    out, other = big.run(a, b, 0.6, steps)
+    torch.cuda.synchronize()
+    del other
+    for ix in range(2):
+        for iy in range(2):
+            for iz in range(2):
+                tile = out[:, ix * n:(ix + 1) * n, iy * n:(iy + 1) * n, iz * n:(iz + 1) * n]
+                assert torch.equal(tile, ref), (ix, iy, iz)
+    m = float(big.mass(out).cpu())
+    assert m == pytest.approx(8 * float(small.mass(ref).cpu()), rel=1e-7)
+
+
 def test_hipgraph_replay_gives_identical_populations():
     """Launch-bound grids replay the fused launches as a captured hipGraph (32 steps per graph);
     the result must be bit-identical to eager launches, also when the graph is reused, when the
