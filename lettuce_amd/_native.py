@@ -89,6 +89,10 @@ SYMBOLS = {
     "lt_plan_set_graph_mode": (ctypes.c_int, [_vp, _i32]),
     "lt_plan_set_tuning": (ctypes.c_int, [_vp, _i32, _i32]),
     "lt_plan_set_residency": (ctypes.c_int, [_vp, _i32]),
+    "lt_stream_collide_twice": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _vp]),
+    "lt_plan_set_two_step": (ctypes.c_int, [_vp, _i32, _i32]),
+    "lt_plan_set_fused_events": (ctypes.c_int, [_vp, _vp, _vp]),
+    "lt_plan_last_run_info": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "lt_probe_copy": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
 }
 
@@ -426,6 +430,33 @@ class Plan:
 
     def set_tuning(self, cache_policy: int = -1, wide: bool = False):
         self._check(self.lib.lt_plan_set_tuning(self._handle, int(cache_policy), int(bool(wide))))
+
+    def set_fused_events(self, start=None, stop=None):
+        """torch.cuda.Event pair recorded by lt_run around its fused launches (None, None: off)"""
+        if start is None:
+            self._check(self.lib.lt_plan_set_fused_events(self._handle, None, None))
+            return
+        for e in (start, stop):
+            e.record()                      # torch creates the hipEvent_t lazily
+        self._check(self.lib.lt_plan_set_fused_events(self._handle, ctypes.c_void_p(start.cuda_event),
+                                                      ctypes.c_void_p(stop.cuda_event)))
+
+    def last_run_info(self):
+        single, twice = ctypes.c_int64(), ctypes.c_int64()
+        self._check(self.lib.lt_plan_last_run_info(self._handle, ctypes.byref(single), ctypes.byref(twice)))
+        return {"single_step_launches": single.value, "two_step_launches": twice.value}
+
+    def set_two_step(self, mode: int = -1, planes_per_workgroup: int = 0):
+        """lt_run pairs fused steps into two-step launches: -1 automatic, 0 never, 1 when supported"""
+        self._check(self.lib.lt_plan_set_two_step(self._handle, int(mode), int(planes_per_workgroup)))
+
+    @_on_device
+    def stream_collide_twice(self, f, out, tau):
+        """out = (collide o stream)^2 f in one launch (LDS-staged intermediate state)"""
+        self._tensor_ok(f, self.f_shape); self._tensor_ok(out, self.f_shape)
+        self._check(self.lib.lt_stream_collide_twice(self._handle, _ptr(f), _ptr(out), float(tau),
+                                                     _stream_handle()))
+        return out
 
     def set_residency(self, workgroups_per_cu: int = -1):
         """-1 automatic, 0 no cap, 2..8 workgroups resident per CU for the chip-filling launches"""

@@ -192,18 +192,14 @@ class _NativeStepper:
         self._carry = (_version(result), _version(other), tau)
 
     def _batch_with_events(self, f, nxt, tau, k):
-        """Same launches as lt_run, issued one by one so that HIP events can bracket the
-        k-1 fused launches on the launch stream."""
+        """lt_run with the event pair recorded by the engine around its fused launches on the
+        launch stream (lt_plan_set_fused_events); ``last_run_info`` tells what they bracket."""
         start, end = self.fused_events
-        plan = self.plan
-        cur, other = plan.collide(f, nxt, tau), f
-        start.record()
-        for _ in range(k - 1):
-            plan.stream_collide(cur, other, tau)
-            cur, other = other, cur
-        end.record()
-        plan.stream(cur, other)
-        return other, cur
+        self.plan.set_fused_events(start, end)
+        try:
+            return self.plan.run(f, nxt, tau, k)
+        finally:
+            self.plan.set_fused_events(None, None)
 
     def single_step(self, *_, **__):
         self.batch(1)

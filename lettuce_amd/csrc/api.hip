@@ -77,6 +77,10 @@ struct lt_plan {
   int shift;
   int tune = -1;             // cache policy: -1 = automatic
   int residency = -1;        // workgroups per CU of the big launches: -1 = automatic, 0 = no cap
+  int two_step = -1;         // lt_run: pair the fused steps (lbm2_kernel): -1 = automatic, 0 / 1
+  int seg_len = 0;           // planes per workgroup of the two-step kernel, 0 = automatic
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // lt_plan_set_fused_events
+  long long last_single = 0, last_twice = 0;          // fused launches of the last lt_run
   int want_wide = 0;         // 16-byte accesses for the hot kernel (A/B experiments)
   // engine-owned device scratch
   unsigned char *node = nullptr;
@@ -222,6 +226,20 @@ int resolve_lds(const lt_plan *p, long long workgroups) {
   return per_wg > 65536 ? 65536 : per_wg;
 }
 
+// planes per workgroup of the two-step kernel: the longest segment (<= 64 planes; every segment
+// recomputes two extra intermediate planes) that still gives >= 1024 workgroups (4 per CU)
+int resolve_seg_len(const lt_plan *p) {
+  if (p->seg_len > 0) return p->seg_len;
+  const long long tiles = (long long)(p->n0 / 64) * (p->n1 / 8);
+  int best = 0;
+  for (int len = p->n2 < 64 ? p->n2 : 64; len >= 1; --len) {
+    if (p->n2 % len) continue;
+    if (!best) best = len;
+    if (tiles * (p->n2 / len) >= 1024) return len;
+  }
+  return best ? best : 1;
+}
+
 int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long pb, long long pe,
          void *stream, long long stride = 1, void *pack_lo = nullptr, void *pack_hi = nullptr) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
@@ -252,6 +270,7 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.shift = a.wide ? p->shift : 0;
   a.tune = resolve_tune(p, a.wide);
   a.lds_bytes = resolve_lds(p, ((long long)a.planes * a.n1 * a.n0 + 255) / 256);
+  a.seg_len = mode == lt::kFusedTwice ? resolve_seg_len(p) : 0;
   a.stream = static_cast<hipStream_t>(stream);
   a.pack_lo = pack_lo; a.pack_hi = pack_hi;
   a.pack_lo_plane = (int)pb; a.pack_hi_plane = (int)(pb + stride * (a.planes - 1));
@@ -319,6 +338,21 @@ long long run_graph(lt_plan *p, void *cur, void *other, double tau, long long fu
   return reps * kGraphChunk;
 }
 
+// Does lt_run pair its fused steps?  Needs the two-step kernel for this lattice / dtype / collision
+// (asked of the unit by name), a grid that tiles (a0 % 64, a1 % 8) and no masks; "automatic" also
+// asks for the streaming regime (populations beyond the caches), where halving the HBM passes pays.
+bool two_step_wanted(lt_plan *p) {
+  if (p->two_step == 0 || p->masked || p->desc.ghost_planes) return false;
+  if (p->n0 % 64 != 0 || p->n1 % 8 != 0) return false;
+  lt::StepArgs a;
+  memset(&a, 0, sizeof a);
+  a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = lt::kFusedTwice;
+  if (!p->unit.name(a)) return false;
+  if (p->two_step == 1) return true;
+  const long long bytes = 2ll * p->unit.q * p->N * p->esize;
+  return bytes > (128ll << 20);
+}
+
 int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, void *stream,
         int32_t *result_in_b) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
@@ -341,11 +375,26 @@ int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, 
     if (done < 0) return (int)-done;
     fused -= done;                       // an even number of steps: still in `cur`
   }
-  for (long long i = 0; i < fused; ++i) {
+  // fused section: pairs of steps through the two-step kernel where it applies, the rest one by
+  // one.  The optional events bracket the dominant kind of launch only.
+  const long long twice = two_step_wanted(p) ? fused / 2 : 0;
+  const long long single = fused - 2 * twice;
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  p->last_twice = twice; p->last_single = single;
+  if (p->ev_start && twice > 0) (void)hipEventRecord(p->ev_start, hs);
+  for (long long i = 0; i < twice; ++i) {
+    rc = step(p, lt::kFusedTwice, cur, other, tau, 0, p->n2, stream);
+    if (rc) return rc;
+    void *t = cur; cur = other; other = t;
+  }
+  if (p->ev_stop && twice > 0) (void)hipEventRecord(p->ev_stop, hs);
+  if (p->ev_start && twice == 0) (void)hipEventRecord(p->ev_start, hs);
+  for (long long i = 0; i < single; ++i) {
     rc = step(p, lt::kFused, cur, other, tau, 0, p->n2, stream);
     if (rc) return rc;
     void *t = cur; cur = other; other = t;
   }
+  if (p->ev_stop && twice == 0) (void)hipEventRecord(p->ev_stop, hs);
   rc = step(p, lt::kStreamOnly, cur, other, tau, 0, p->n2, stream);
   if (rc) return rc;
   *result_in_b = (other == b) ? 1 : 0;
@@ -565,7 +614,8 @@ const char *lt_plan_kernel_name(lt_plan *p) {
   if (!p) return "";
   lt::StepArgs a;
   memset(&a, 0, sizeof a);
-  a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = lt::kFused;
+  a.layout = p->desc.layout; a.coll = p->desc.collision;
+  a.mode = two_step_wanted(p) ? lt::kFusedTwice : lt::kFused;   // what lt_run's fused section launches
   a.masked = p->masked;
   a.wide = (p->want_wide && p->wide_ok && !a.masked && a.coll == LT_COLLISION_BGK) ? 1 : 0;
   a.shift = a.wide ? p->shift : 0;
@@ -621,6 +671,37 @@ int lt_plan_set_graph_mode(lt_plan *p, int32_t mode) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (mode < -1 || mode > 1) return fail(LT_ERR_INVALID, "graph mode %d", mode);
   p->graph_mode = mode;
+  return LT_OK;
+}
+
+int lt_stream_collide_twice(lt_plan *p, const void *f, void *out, double tau, void *stream) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  return step(p, lt::kFusedTwice, f, out, tau, 0, p->n2, stream);
+}
+
+int lt_plan_set_fused_events(lt_plan *p, void *start_event, void *stop_event) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if ((start_event == nullptr) != (stop_event == nullptr))
+    return fail(LT_ERR_INVALID, "give both events or neither");
+  p->ev_start = static_cast<hipEvent_t>(start_event);
+  p->ev_stop = static_cast<hipEvent_t>(stop_event);
+  return LT_OK;
+}
+
+int lt_plan_last_run_info(lt_plan *p, int64_t *single_step_launches, int64_t *two_step_launches) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (single_step_launches) *single_step_launches = p->last_single;
+  if (two_step_launches) *two_step_launches = p->last_twice;
+  return LT_OK;
+}
+
+int lt_plan_set_two_step(lt_plan *p, int32_t mode, int32_t planes_per_workgroup) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (mode < -1 || mode > 1) return fail(LT_ERR_INVALID, "two-step mode %d", mode);
+  if (planes_per_workgroup < 0 || (planes_per_workgroup > 0 && p->n2 % planes_per_workgroup != 0))
+    return fail(LT_ERR_INVALID, "planes per workgroup %d does not divide %d", planes_per_workgroup, p->n2);
+  p->two_step = mode;
+  p->seg_len = planes_per_workgroup;
   return LT_OK;
 }
 

@@ -743,6 +743,107 @@ __global__ void __launch_bounds__(kThreads, 4) lbm_kernel_occ4(const KParams<T> 
   lbm_body<T, S, LAYOUT, COLL, STREAM, COLLIDE, MASKED, VEC, SHIFT, TUNE, PACK>(p);
 }
 
+// ---- two fused steps per launch (periodic, no masks) -----------------------------------------
+// f*_out = (C S)^2 f*_in with the intermediate state held in LDS, so that HBM sees one read and one
+// write of the populations per TWO lattice updates.  A workgroup owns a T0 x T1 column of nodes in
+// (a0, a1) and sweeps seg_len planes along a2:
+//   phase A(k+1): every thread pulls one node of the (T0+2) x (T1+2) halo'd tile of plane k+1 from
+//                 global memory (the ordinary gather), collides it and writes it to one of three
+//                 LDS plane slots;
+//   phase B(k):   the first T0*T1 threads pull their node of plane k from the LDS planes k-1, k,
+//                 k+1, collide and store to global memory.
+// The global loads for A(k+2) are issued before the barrier and land while B(k) computes; the
+// barrier waits for LDS traffic only (an ordinary __syncthreads() would drain the loads).
+// Arithmetic per node is the one-step kernel's (same gather, same collide): results are bit for
+// bit those of two lbm_kernel launches.  Redundant work: (T0+2)(T1+2)/(T0 T1) in the first step
+// and two extra planes per segment.
+template <typename T, class S, int T1>
+struct TwoStep {
+  static constexpr int T0 = 64, H0 = T0 + 2, H1 = T1 + 2;
+  static constexpr int NI = H0 * H1;                    // intermediate nodes per plane
+  static constexpr int NO = T0 * T1;                    // output nodes per plane
+  static constexpr int THREADS = (NI + 63) / 64 * 64;
+  static constexpr size_t LDS_BYTES = sizeof(T) * 3 * S::Q * NI;
+};
+
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename T, class S, int LAYOUT, int COLL, int T1>
+__global__ void __launch_bounds__((TwoStep<T, S, T1>::THREADS))
+lbm2_kernel(const KParams<T> p, const int seg_len) {
+  using B = TwoStep<T, S, T1>;
+  using M = MemMap<S, LAYOUT>;
+  constexpr int T0 = B::T0, H0 = B::H0, NI = B::NI, NO = B::NO;
+  static_assert(COLL == 0 || COLL == 1, "two-step kernel: streaming only or BGK");
+  __shared__ T lds[3][S::Q][NI];
+
+  const int tid = threadIdx.x;
+  const int tiles0 = p.n0 / T0, tiles1 = p.n1 / T1;
+  int b = blockIdx.x;
+  const int t0 = (b % tiles0) * T0; b /= tiles0;
+  const int t1 = (b % tiles1) * T1; b /= tiles1;
+  const int s = b * seg_len;                       // first output plane of this workgroup
+
+  // phase A: node (i0, i1) of the halo'd tile, global coordinates (g0, g1)
+  const bool in_a = tid < NI;
+  const int i1 = tid / H0, i0 = tid - i1 * H0;
+  int g0 = t0 + i0 - 1; g0 = g0 < 0 ? g0 + p.n0 : (g0 >= p.n0 ? g0 - p.n0 : g0);
+  int g1 = t1 + i1 - 1; g1 = g1 < 0 ? g1 + p.n1 : (g1 >= p.n1 ? g1 - p.n1 : g1);
+  // phase B: output node (j0, j1) of the tile
+  const bool in_b = tid < NO;
+  const int j1 = tid / T0, j0 = tid - j1 * T0;
+
+  T pre[S::Q][1];
+  auto load_a = [&](int plane) {
+    if (in_a) {
+      const int g2 = plane < 0 ? plane + p.n2 : (plane >= p.n2 ? plane - p.n2 : plane);
+      const Coord c = make_coord(p, g0, g1, g2);
+      gather<T, S, LAYOUT, true, 1, 0, false>(p, c, pre);
+    }
+  };
+  auto compute_a = [&](int slot) {
+    if (in_a) {
+      if constexpr (COLL == 1) collide_bgk<T, S, LAYOUT, 1, 0>(pre, p.tau_inv);
+      static_for<S::Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        lds[slot][q][tid] = pre[q][0];
+      });
+    }
+  };
+  auto step_b = [&](int k, int sm, int sc, int sp) {
+    if (in_b) {
+      T f[S::Q][1];
+      static_for<S::Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1), e2 = M::e(q, 2);
+        const int slot = e2 == 0 ? sc : (e2 > 0 ? sm : sp);
+        f[q][0] = lds[slot][q][(j1 + 1 - e1) * H0 + (j0 + 1 - e0)];
+      });
+      if constexpr (COLL == 1) collide_bgk<T, S, LAYOUT, 1, 0>(f, p.tau_inv);
+      const unsigned own = (unsigned)(k * p.n1 + t1 + j1) * (unsigned)p.n0 + (unsigned)(t0 + j0);
+      static_for<S::Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        vstore<T, 1, true>(p.out + (long long)q * p.N + own, f[q]);
+      });
+    }
+  };
+
+  load_a(s - 1); compute_a(0);
+  load_a(s);     compute_a(1);
+  load_a(s + 1);
+  int sm = 0, sc = 1, sp = 2;
+  for (int k = s; k < s + seg_len; ++k) {
+    compute_a(sp);                                  // intermediate plane k + 1
+    if (k + 1 < s + seg_len) load_a(k + 2);         // in flight across the barrier and phase B
+    lds_barrier();
+    step_b(k, sm, sc, sp);
+    lds_barrier();
+    const int t = sm; sm = sc; sc = sp; sp = t;
+  }
+}
+
 // ---- auxiliary kernels --------------------------------------------------------------------
 // rho [N], u [d][N] (logical axis order) from f  -- Flow.rho / Flow.u
 template <typename T, class S, int LAYOUT>

@@ -7,16 +7,23 @@ reports exactly half of the bytes of a wide coalesced streaming read, WRITE_SIZE
 streaming stores.  The factor is calibrated in-run on the collide-only kernel
 (lbm_kernel<..., false, true, ...>), which reads every population exactly once with the same
 access width as the fused kernel: factor = algorithmic read bytes / (FETCH_SIZE * 1024).
+The two-step kernel (lbm2_kernel) loads with the same 4 bytes per lane; its FETCH_SIZE (L2 misses,
+Infinity-Cache hits included) is scaled by the same factor.  Its algorithmic bytes are those of the
+two lattice updates per node it performs per launch.
 """
 import csv, glob, json, os, statistics, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def is_lbm(name):
+    return "lt::lbm_kernel" in name or "lt::lbm2_kernel" in name
+
+
 def pmc(path):
     out = {}
     for row in csv.DictReader(open(path)):
-        if "lbm_kernel" in row["Kernel_Name"]:
+        if is_lbm(row["Kernel_Name"]):
             out.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
     return {k: statistics.median(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
 
@@ -27,8 +34,8 @@ def main(tag, nodes=256 ** 3, q=19, esize=4, workload="tgv3d_d3q19_bgk_f32_256")
     os.makedirs(dst, exist_ok=True)
     stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
     rows = list(csv.reader(open(stats)))
-    keep = [rows[0]] + [r for r in rows[1:] if "lbm_kernel" in r[0]] + \
-           [r for r in rows[1:8] if "lbm_kernel" not in r[0]]
+    keep = [rows[0]] + [r for r in rows[1:] if is_lbm(r[0])] + \
+           [r for r in rows[1:8] if not is_lbm(r[0])]
     with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
         csv.writer(fh, quoting=csv.QUOTE_ALL).writerows(keep)
     fetch, n_f = pmc(glob.glob(os.path.join(src, "pmc_FETCH_SIZE", "*", "*_counter_collection.csv"))[0])
@@ -40,13 +47,15 @@ def main(tag, nodes=256 ** 3, q=19, esize=4, workload="tgv3d_d3q19_bgk_f32_256")
     for k in sorted(fetch):
         rd = fetch[k] * 1024 * factor
         wr = write.get(k, float("nan")) * 1024
+        updates = 2 if "lbm2_kernel" in k else 1     # the two-step kernel does two lattice updates per node
         kernels.append({"kernel": k, "workload": workload, "launches_sampled": n_f[k],
                         "FETCH_SIZE_KiB_median": fetch[k], "WRITE_SIZE_KiB_median": write.get(k),
                         "fetch_correction_factor": round(factor, 4),
                         "hbm_read_bytes_per_launch": round(rd), "hbm_write_bytes_per_launch": round(wr),
                         "hbm_bytes_per_launch": round(rd + wr),
-                        "algorithmic_bytes_per_launch": 2 * alg,
-                        "traffic_over_algorithmic": round((rd + wr) / (2 * alg), 4)})
+                        "lattice_updates_per_node_per_launch": updates,
+                        "algorithmic_bytes_per_launch": updates * 2 * alg,
+                        "traffic_over_algorithmic": round((rd + wr) / (updates * 2 * alg), 4)})
     json.dump({"tag": tag, "note": __doc__.split("gfx950 corrections")[1].strip(), "kernels": kernels},
               open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     for k in kernels:
@@ -59,7 +68,7 @@ def main(tag, nodes=256 ** 3, q=19, esize=4, workload="tgv3d_d3q19_bgk_f32_256")
             continue
         acc = {}
         for row in csv.DictReader(open(files[0])):
-            if "lbm_kernel" in row["Kernel_Name"]:
+            if is_lbm(row["Kernel_Name"]):
                 acc.setdefault(row["Kernel_Name"], {}).setdefault(row["Counter_Name"], []).append(
                     float(row["Counter_Value"]))
         for kname, counters in acc.items():
