@@ -77,6 +77,7 @@ struct lt_plan {
   int shift;
   int tune = -1;             // cache policy: -1 = automatic
   int residency = -1;        // workgroups per CU of the big launches: -1 = automatic, 0 = no cap
+  int n_cu = 0;              // compute units of the plan's device
   int two_step = -1;         // lt_run: pair the fused steps (lbm2_kernel): -1 = automatic, 0 / 1
   int seg_len = 0;           // planes per workgroup of the two-step kernel, 0 = automatic
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // lt_plan_set_fused_events
@@ -226,18 +227,25 @@ int resolve_lds(const lt_plan *p, long long workgroups) {
   return per_wg > 65536 ? 65536 : per_wg;
 }
 
-// planes per workgroup of the two-step kernel: the longest segment (<= 64 planes; every segment
-// recomputes two extra intermediate planes) that still gives >= 1024 workgroups (4 per CU)
+// planes per workgroup of the two-step kernel.  One workgroup occupies a CU (150 KB of LDS), so the
+// launch runs in rounds of n_cu workgroups; a segment of L planes computes L + 2 intermediate
+// planes.  Pick the divisor L of n2 with the best (L / (L + 2)) * (blocks / blocks rounded up to
+// whole rounds): 128 planes = 256 workgroups at 256^3 (measured 0.3345 ms per step against 0.3412
+// with 32 planes and 0.52 with 256, which leaves half the CUs idle).
 int resolve_seg_len(const lt_plan *p) {
   if (p->seg_len > 0) return p->seg_len;
   const long long tiles = (long long)(p->n0 / 64) * (p->n1 / 8);
-  int best = 0;
-  for (int len = p->n2 < 64 ? p->n2 : 64; len >= 1; --len) {
+  const long long cus = p->n_cu > 0 ? p->n_cu : 256;
+  int best = 1;
+  double best_score = -1.0;
+  for (int len = 1; len <= p->n2; ++len) {
     if (p->n2 % len) continue;
-    if (!best) best = len;
-    if (tiles * (p->n2 / len) >= 1024) return len;
+    const long long blocks = tiles * (p->n2 / len);
+    const long long rounds = (blocks + cus - 1) / cus;
+    const double score = ((double)len / (len + 2)) * ((double)blocks / (double)(rounds * cus));
+    if (score > best_score) { best_score = score; best = len; }
   }
-  return best ? best : 1;
+  return best;
 }
 
 int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long pb, long long pe,
@@ -271,6 +279,7 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.tune = resolve_tune(p, a.wide);
   a.lds_bytes = resolve_lds(p, ((long long)a.planes * a.n1 * a.n0 + 255) / 256);
   a.seg_len = mode == lt::kFusedTwice ? resolve_seg_len(p) : 0;
+  if (mode == lt::kFusedTwice) a.shift = p->shift;      // tile-shape A/B variant
   a.stream = static_cast<hipStream_t>(stream);
   a.pack_lo = pack_lo; a.pack_hi = pack_hi;
   a.pack_lo_plane = (int)pb; a.pack_hi_plane = (int)(pb + stride * (a.planes - 1));
@@ -469,6 +478,12 @@ int lt_plan_create(const lt_plan_desc *d, lt_plan **out) {
   p->interior_end = p->n2 - d->ghost_planes;
   p->wide_ok = (e0 % (16 / p->esize)) == 0;
   p->shift = 0;
+  {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+      p->n_cu = cus;
+  }
   int n_abb = 0;
   for (int i = 0; i < d->n_boundaries; ++i) {
     const int rc = check_boundary(p, d->boundaries[i], n_abb);

@@ -747,19 +747,21 @@ __global__ void __launch_bounds__(kThreads, 4) lbm_kernel_occ4(const KParams<T> 
 // f*_out = (C S)^2 f*_in with the intermediate state held in LDS, so that HBM sees one read and one
 // write of the populations per TWO lattice updates.  A workgroup owns a T0 x T1 column of nodes in
 // (a0, a1) and sweeps seg_len planes along a2:
-//   phase A(k+1): every thread pulls one node of the (T0+2) x (T1+2) halo'd tile of plane k+1 from
+//   phase A(k):   every thread pulls one node of the (T0+2) x (T1+2) halo'd tile of plane k from
 //                 global memory (the ordinary gather), collides it and writes it to one of three
 //                 LDS plane slots;
 //   phase B(k):   the first T0*T1 threads pull their node of plane k from the LDS planes k-1, k,
 //                 k+1, collide and store to global memory.
-// The global loads for A(k+2) are issued before the barrier and land while B(k) computes; the
-// barrier waits for LDS traffic only (an ordinary __syncthreads() would drain the loads).
+// Per plane: barrier, the 19 LDS reads of B(k), barrier, then one long barrier-free stretch --
+// collide and store B(k), collide A(k+2) into the slot of plane k-1, issue the global loads of
+// A(k+3), which land while the next plane is processed.  The barriers wait for LDS traffic only
+// (an ordinary __syncthreads() would drain the prefetch).
 // Arithmetic per node is the one-step kernel's (same gather, same collide): results are bit for
 // bit those of two lbm_kernel launches.  Redundant work: (T0+2)(T1+2)/(T0 T1) in the first step
 // and two extra planes per segment.
-template <typename T, class S, int T1>
+template <typename T, class S, int T0_, int T1>
 struct TwoStep {
-  static constexpr int T0 = 64, H0 = T0 + 2, H1 = T1 + 2;
+  static constexpr int T0 = T0_, H0 = T0 + 2, H1 = T1 + 2;
   static constexpr int NI = H0 * H1;                    // intermediate nodes per plane
   static constexpr int NO = T0 * T1;                    // output nodes per plane
   static constexpr int THREADS = (NI + 63) / 64 * 64;
@@ -770,10 +772,10 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename T, class S, int LAYOUT, int COLL, int T1>
-__global__ void __launch_bounds__((TwoStep<T, S, T1>::THREADS))
+template <typename T, class S, int LAYOUT, int COLL, int T0_, int T1>
+__global__ void __launch_bounds__((TwoStep<T, S, T0_, T1>::THREADS))
 lbm2_kernel(const KParams<T> p, const int seg_len) {
-  using B = TwoStep<T, S, T1>;
+  using B = TwoStep<T, S, T0_, T1>;
   using M = MemMap<S, LAYOUT>;
   constexpr int T0 = B::T0, H0 = B::H0, NI = B::NI, NO = B::NO;
   static_assert(COLL == 0 || COLL == 1, "two-step kernel: streaming only or BGK");
@@ -812,15 +814,19 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
       });
     }
   };
-  auto step_b = [&](int k, int sm, int sc, int sp) {
+  T f[S::Q][1];
+  auto read_b = [&](int sm, int sc, int sp) {       // planes k-1, k, k+1
     if (in_b) {
-      T f[S::Q][1];
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1), e2 = M::e(q, 2);
         const int slot = e2 == 0 ? sc : (e2 > 0 ? sm : sp);
         f[q][0] = lds[slot][q][(j1 + 1 - e1) * H0 + (j0 + 1 - e0)];
       });
+    }
+  };
+  auto finish_b = [&](int k) {
+    if (in_b) {
       if constexpr (COLL == 1) collide_bgk<T, S, LAYOUT, 1, 0>(f, p.tau_inv);
       const unsigned own = (unsigned)(k * p.n1 + t1 + j1) * (unsigned)p.n0 + (unsigned)(t0 + j0);
       static_for<S::Q>([&](auto qc) {
@@ -830,16 +836,22 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
     }
   };
 
+  // intermediate planes s-1 .. s+seg_len are needed; three are resident at any time
+  const int last = s + seg_len;
   load_a(s - 1); compute_a(0);
   load_a(s);     compute_a(1);
-  load_a(s + 1);
+  load_a(s + 1); compute_a(2);
+  if (s + 2 <= last) load_a(s + 2);
   int sm = 0, sc = 1, sp = 2;
-  for (int k = s; k < s + seg_len; ++k) {
-    compute_a(sp);                                  // intermediate plane k + 1
-    if (k + 1 < s + seg_len) load_a(k + 2);         // in flight across the barrier and phase B
-    lds_barrier();
-    step_b(k, sm, sc, sp);
-    lds_barrier();
+  for (int k = s; k < last; ++k) {
+    lds_barrier();                                  // intermediate plane k + 1 is complete
+    read_b(sm, sc, sp);
+    lds_barrier();                                  // everybody has read plane k - 1: its slot is free
+    finish_b(k);
+    if (k + 2 <= last) {
+      compute_a(sm);                                // intermediate plane k + 2 replaces plane k - 1
+      if (k + 3 <= last) load_a(k + 3);             // lands during the next iteration's phase B
+    }
     const int t = sm; sm = sc; sc = sp; sp = t;
   }
 }

@@ -452,3 +452,61 @@ def test_cfg1_populations_bit_identical_after_100_steps():
     g = golden("tgv2d_d2q9_bgk_128_f64")
     plan = plan_for("D2Q9", torch.float64, "bgk", [128, 128])
     np.testing.assert_array_equal(run_engine(plan, g["f0"], float(g["tau"]), 100), g["f100"])
+
+
+# --------------------------------------------------------------------------- two steps per launch
+@pytest.mark.parametrize("res,seg", [([4, 8, 64], 0), ([8, 16, 64], 4), ([6, 24, 128], 3), ([1, 8, 64], 1),
+                                     ([12, 40, 192], 0), ([5, 8, 64], 5)])
+@pytest.mark.parametrize("coll", ["none", "bgk"])
+def test_two_step_launch_is_bit_identical_to_two_single_steps(res, seg, coll):
+    """lt_stream_collide_twice (intermediate state in LDS, halo'd tiles, plane sweep with wrap) against
+    two lt_stream_collide launches: every segment length incl. 1, tiles that wrap in both tiled
+    axes, several tiles per axis."""
+    plan = plan_for("D3Q19", torch.float32, coll, res)
+    plan.set_two_step(1, seg)
+    torch.manual_seed(3)
+    w = torch.rand(19, 1, 1, 1, device="cuda") * 0.05 + 0.02
+    f = (w * (1 + 0.1 * torch.rand(plan.f_shape, device="cuda"))).contiguous()
+    a, b, c = torch.empty_like(f), torch.empty_like(f), torch.empty_like(f)
+    plan.stream_collide(f, a, 0.6)
+    plan.stream_collide(a, b, 0.6)
+    plan.stream_collide_twice(f, c, 0.6)
+    assert torch.equal(b, c)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 7, 8])
+def test_lt_run_with_paired_steps_equals_lt_run_without(n):
+    """odd and even numbers of fused steps: pairs through the two-step kernel plus a single one"""
+    res = [8, 16, 64]
+    L = orc.LATTICES["D3Q19"]
+    torch.manual_seed(5)
+    w = torch.tensor(L.w, dtype=torch.float32, device="cuda").reshape(19, 1, 1, 1)
+    f0 = (w * (1 + 0.1 * torch.rand([19] + res, device="cuda"))).contiguous()
+    outs = []
+    for mode in (0, 1):
+        plan = plan_for("D3Q19", torch.float32, "bgk", res)
+        plan.set_two_step(mode)
+        r, other = plan.run(f0.clone(), torch.empty_like(f0), 0.7, n)
+        info = plan.last_run_info()
+        assert info["two_step_launches"] == (mode * ((n - 1) // 2))
+        assert info["single_step_launches"] == (n - 1) - 2 * info["two_step_launches"]
+        outs.append((r.clone(), other.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])        # post-streaming populations
+    assert torch.equal(outs[0][1], outs[1][1])        # post-collision populations of the last step
+    ref = orc.OracleSimulation(L, f0.cpu().clone(), "bgk", 0.7)
+    ref.step(n)
+    assert_close(outs[1][0].cpu().numpy(), ref.f.numpy(), "f32")
+
+
+def test_two_step_unsupported_combinations_fail_loudly():
+    from lettuce_amd._native import NativeEngineError
+    for lat, dt, coll, res in (("D3Q27", torch.float32, "bgk", [4, 8, 64]), ("D3Q19", torch.float64, "bgk", [4, 8, 64]),
+                               ("D3Q19", torch.float32, "bgk", [4, 8, 60]), ("D3Q19", torch.float32, "bgk", [4, 6, 64])):
+        plan = plan_for(lat, dt, coll, res)
+        f = torch.rand(plan.f_shape, device="cuda", dtype=dt)
+        with pytest.raises(NativeEngineError):
+            plan.stream_collide_twice(f, torch.empty_like(f), 0.6)
+        # lt_run falls back to single steps by itself
+        plan.set_two_step(1)
+        plan.run(f, torch.empty_like(f), 0.6, 4)
+        assert plan.last_run_info()["two_step_launches"] == 0

@@ -38,25 +38,23 @@ plan = Plan("D3Q19", torch.float32, "bgk", res, [], device=torch.device("cuda:0"
 f = torch.rand(plan.f_shape, device="cuda") * 0.01 + 0.05
 g = torch.empty_like(f)
 out = {}
+variants = [("single", -1, 0)] + [(f"v{v}_seg{seg}", seg, v) for v in (0, 1) for seg in (32, 64, 128)]
 for r in range(5):
-    for seg in (-1, 8, 16, 32, 64, 128, 256):
+    for label, seg, variant in variants:
         if seg > 0:
             plan.set_two_step(1, seg)
+            plan.set_shift_policy(variant)
         e0, e1 = ev(), ev()
         a, b = f, g
-        for _ in range(2):
-            if seg < 0:
-                plan.stream_collide(a, b, 0.6); a, b = b, a
-                plan.stream_collide(a, b, 0.6); a, b = b, a
-            else:
-                plan.stream_collide_twice(a, b, 0.6); a, b = b, a
-        e0.record()
-        for _ in range(10):
+        for it in range(12):
+            if it == 2:
+                e0.record()
             if seg < 0:
                 plan.stream_collide(a, b, 0.6); a, b = b, a
                 plan.stream_collide(a, b, 0.6); a, b = b, a
             else:
                 plan.stream_collide_twice(a, b, 0.6); a, b = b, a
         e1.record(); torch.cuda.synchronize()
-        out.setdefault(seg, []).append(e0.elapsed_time(e1) / 20)
-print(json.dumps({"ms_per_step_by_seg_len (-1 = two single steps)": {k: round(sorted(v)[2], 4) for k, v in out.items()}}), flush=True)
+        out.setdefault(label, []).append(e0.elapsed_time(e1) / 20)
+plan.set_shift_policy(0)
+print(json.dumps({"ms_per_step": {k: round(sorted(v)[2], 4) for k, v in out.items()}}), flush=True)
