@@ -753,8 +753,8 @@ __global__ void __launch_bounds__(kThreads, 4) lbm_kernel_occ4(const KParams<T> 
 //   phase B(k):   the first T0*T1 threads pull their node of plane k from the LDS planes k-1, k,
 //                 k+1, collide and store to global memory.
 // Per plane: barrier, the 19 LDS reads of B(k), barrier, then one long barrier-free stretch --
-// collide and store B(k), collide A(k+2) into the slot of plane k-1, issue the global loads of
-// A(k+3), which land while the next plane is processed.  The barriers wait for LDS traffic only
+// collide B(k), collide A(k+2) into the slot of plane k-1, issue the global loads of A(k+3), which
+// land while the next plane is processed, store B(k).  The barriers wait for LDS traffic only
 // (an ordinary __syncthreads() would drain the prefetch).
 // Arithmetic per node is the one-step kernel's (same gather, same collide): results are bit for
 // bit those of two lbm_kernel launches.  Redundant work: (T0+2)(T1+2)/(T0 T1) in the first step
@@ -797,12 +797,36 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   const bool in_b = tid < NO;
   const int j1 = tid / T0, j0 = tid - j1 * T0;
 
+  // Addresses: the plane part is uniform (scalar registers, recomputed per plane), the in-plane
+  // part is a per-thread constant -- nine byte offsets for the nine (e0, e1) pairs of the lattice --
+  // so that a load is "scalar base + 32-bit vector offset" with no vector arithmetic in the loop.
+  const int g0m = g0 == 0 ? p.n0 - 1 : g0 - 1, g0p = g0 == p.n0 - 1 ? 0 : g0 + 1;
+  const int g1m = g1 == 0 ? p.n1 - 1 : g1 - 1, g1p = g1 == p.n1 - 1 ? 0 : g1 + 1;
+  unsigned voff[3][3];                               // [e1 + 1][e0 + 1], bytes within a plane
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int y = a == 0 ? g1p : (a == 1 ? g1 : g1m);     // source = node - e
+      const int x = c == 0 ? g0p : (c == 1 ? g0 : g0m);
+      voff[a][c] = ((unsigned)y * (unsigned)p.n0 + (unsigned)x) * (unsigned)sizeof(T);
+    }
+  const unsigned plane_nodes = (unsigned)p.n1 * (unsigned)p.n0;
+  const unsigned out_off = ((unsigned)(t1 + j1) * (unsigned)p.n0 + (unsigned)(t0 + j0)) * (unsigned)sizeof(T);
+
   T pre[S::Q][1];
   auto load_a = [&](int plane) {
+    const int g2 = plane < 0 ? plane + p.n2 : (plane >= p.n2 ? plane - p.n2 : plane);
+    const int g2m = g2 == 0 ? p.n2 - 1 : g2 - 1, g2p = g2 == p.n2 - 1 ? 0 : g2 + 1;
     if (in_a) {
-      const int g2 = plane < 0 ? plane + p.n2 : (plane >= p.n2 ? plane - p.n2 : plane);
-      const Coord c = make_coord(p, g0, g1, g2);
-      gather<T, S, LAYOUT, true, 1, 0, false>(p, c, pre);
+      static_for<S::Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1), e2 = M::e(q, 2);
+        const int z = e2 == 0 ? g2 : (e2 > 0 ? g2m : g2p);
+        // 32-bit scalar multiply (a plane's first node index fits: N < 2^31), 64-bit scalar add
+        const T *base = p.in + ((long long)q * p.N + (long long)((unsigned)z * plane_nodes));
+        pre[q][0] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + voff[e1 + 1][e0 + 1]);
+      });
     }
   };
   auto compute_a = [&](int slot) {
@@ -825,13 +849,17 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
       });
     }
   };
-  auto finish_b = [&](int k) {
+  auto collide_b = [&]() {
     if (in_b) {
       if constexpr (COLL == 1) collide_bgk<T, S, LAYOUT, 1, 0>(f, p.tau_inv);
-      const unsigned own = (unsigned)(k * p.n1 + t1 + j1) * (unsigned)p.n0 + (unsigned)(t0 + j0);
+    }
+  };
+  auto store_b = [&](int k) {
+    if (in_b) {
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        vstore<T, 1, true>(p.out + (long long)q * p.N + own, f[q]);
+        T *base = p.out + ((long long)q * p.N + (long long)((unsigned)k * plane_nodes));
+        __builtin_nontemporal_store(f[q][0], reinterpret_cast<T *>(reinterpret_cast<char *>(base) + out_off));
       });
     }
   };
@@ -847,11 +875,15 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
     lds_barrier();                                  // intermediate plane k + 1 is complete
     read_b(sm, sc, sp);
     lds_barrier();                                  // everybody has read plane k - 1: its slot is free
-    finish_b(k);
+    // All global-memory instructions of a plane are issued together at its end, the loads first:
+    // the vmcnt waits in front of compute_a then only ever meet operations that had the whole of
+    // collide_b to complete (stores issued right before them would be waited for one by one).
+    collide_b();
     if (k + 2 <= last) {
       compute_a(sm);                                // intermediate plane k + 2 replaces plane k - 1
-      if (k + 3 <= last) load_a(k + 3);             // lands during the next iteration's phase B
+      if (k + 3 <= last) load_a(k + 3);             // lands during the next plane
     }
+    store_b(k);
     const int t = sm; sm = sc; sc = sp; sp = t;
   }
 }
