@@ -783,7 +783,11 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
 
   const int tid = threadIdx.x;
   const int tiles0 = p.n0 / T0, tiles1 = p.n1 / T1;
+  // Workgroups go to the 8 XCDs round-robin (block b -> XCD b % 8) and every XCD has its own L2.
+  // Renumber so that an XCD owns a compact patch of neighbouring tiles: the halo rows two tiles
+  // share are then fetched into one L2 once instead of into two L2s.
   int b = blockIdx.x;
+  if (p.nb == 0 && gridDim.x % 8 == 0) b = (b % 8) * (gridDim.x / 8) + b / 8;
   const int t0 = (b % tiles0) * T0; b /= tiles0;
   const int t1 = (b % tiles1) * T1; b /= tiles1;
   const int s = b * seg_len;                       // first output plane of this workgroup

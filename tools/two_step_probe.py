@@ -38,7 +38,7 @@ plan = Plan("D3Q19", torch.float32, "bgk", res, [], device=torch.device("cuda:0"
 f = torch.rand(plan.f_shape, device="cuda") * 0.01 + 0.05
 g = torch.empty_like(f)
 out = {}
-variants = [("single", -1, 0)] + [(f"v{v}_seg{seg}", seg, v) for v in (0, 1) for seg in (32, 64, 128)]
+variants = [("single", -1, 0)] + [(f"v{v}_seg{seg}", seg, v) for v in (0, 2) for seg in (32, 64, 128)]
 for r in range(5):
     for label, seg, variant in variants:
         if seg > 0:
@@ -57,4 +57,16 @@ for r in range(5):
         e1.record(); torch.cuda.synchronize()
         out.setdefault(label, []).append(e0.elapsed_time(e1) / 20)
 plan.set_shift_policy(0)
+none = Plan("D3Q19", torch.float32, "none", res, [], device=torch.device("cuda:0"))
+none.set_two_step(1, 128)
+for r in range(5):
+    for label, fn in (("none_single", lambda a, b: (none.stream_collide(a, b, 1.0), none.stream_collide(b, a, 1.0))),
+                      ("none_twice", lambda a, b: (none.stream_collide_twice(a, b, 1.0), none.stream_collide_twice(b, a, 1.0)))):
+        e0, e1 = ev(), ev()
+        fn(f, g)
+        e0.record()
+        for it in range(5):
+            fn(f, g)
+        e1.record(); torch.cuda.synchronize()
+        out.setdefault(label, []).append(e0.elapsed_time(e1) / (20 if label == "none_twice" else 10))
 print(json.dumps({"ms_per_step": {k: round(sorted(v)[2], 4) for k, v in out.items()}}), flush=True)
