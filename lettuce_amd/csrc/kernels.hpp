@@ -747,25 +747,34 @@ __global__ void __launch_bounds__(kThreads, 4) lbm_kernel_occ4(const KParams<T> 
 // f*_out = (C S)^2 f*_in with the intermediate state held in LDS, so that HBM sees one read and one
 // write of the populations per TWO lattice updates.  A workgroup owns a T0 x T1 column of nodes in
 // (a0, a1) and sweeps seg_len planes along a2:
-//   phase A(k):   every thread pulls one node of the (T0+2) x (T1+2) halo'd tile of plane k from
-//                 global memory (the ordinary gather), collides it and writes it to one of three
-//                 LDS plane slots;
+//   phase A(j):   every thread pulls one node of the (T0+2) x (T1+2) halo'd tile of plane j from
+//                 global memory, collides it and writes its populations to LDS;
 //   phase B(k):   the first T0*T1 threads pull their node of plane k from the LDS planes k-1, k,
 //                 k+1, collide and store to global memory.
-// Per plane: barrier, the 19 LDS reads of B(k), barrier, then one long barrier-free stretch --
-// collide B(k), collide A(k+2) into the slot of plane k-1, issue the global loads of A(k+3), which
-// land while the next plane is processed, store B(k).  The barriers wait for LDS traffic only
-// (an ordinary __syncthreads() would drain the prefetch).
-// Arithmetic per node is the one-step kernel's (same gather, same collide): results are bit for
-// bit those of two lbm_kernel launches.  Redundant work: (T0+2)(T1+2)/(T0 T1) in the first step
-// and two extra planes per segment.
+// B(k) reads the populations moving up (e2 = +1, "U") only from plane k-1, the in-plane ones ("C")
+// only from plane k and those moving down ("D") only from plane k+1.  With 4 LDS slots for U, 3 for
+// C and 2 for D -- 57 population planes, as many as three whole planes -- A(k+2) can write while
+// other waves still read for B(k), and ONE barrier per plane is enough:
+//   barrier; LDS reads of B(k); collide B(k); collide A(k+2) -> LDS; issue the global loads of
+//   A(k+3) (they land during the next plane); store B(k).
+// The barrier waits for LDS traffic only (an ordinary __syncthreads() would drain the prefetch), and
+// all global-memory instructions of a plane are issued together at its end, loads first, so that
+// the vmcnt waits in front of A never meet stores issued just before them.
+// Arithmetic per node is the one-step kernel's (same pull, same collide): results are bit for bit
+// those of two lbm_kernel launches.  Redundant work: (T0+2)(T1+2)/(T0 T1) in the first step and
+// two extra planes per segment.  HBM traffic (PMC, 256^3): reads 1.13x one pass, writes 1.00x.
 template <typename T, class S, int T0_, int T1>
 struct TwoStep {
   static constexpr int T0 = T0_, H0 = T0 + 2, H1 = T1 + 2;
   static constexpr int NI = H0 * H1;                    // intermediate nodes per plane
   static constexpr int NO = T0 * T1;                    // output nodes per plane
   static constexpr int THREADS = (NI + 63) / 64 * 64;
-  static constexpr size_t LDS_BYTES = sizeof(T) * 3 * S::Q * NI;
+  template <int LAYOUT, int E2>
+  static constexpr int count() {                        // populations with e along a2 == E2
+    int n = 0;
+    for (int q = 0; q < S::Q; ++q) n += MemMap<S, LAYOUT>::e(q, 2) == E2 ? 1 : 0;
+    return n;
+  }
 };
 
 __device__ __forceinline__ void lds_barrier() {
@@ -778,8 +787,12 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   using B = TwoStep<T, S, T0_, T1>;
   using M = MemMap<S, LAYOUT>;
   constexpr int T0 = B::T0, H0 = B::H0, NI = B::NI, NO = B::NO;
+  constexpr int NU = B::template count<LAYOUT, 1>(), NC = B::template count<LAYOUT, 0>(),
+                ND = B::template count<LAYOUT, -1>();
   static_assert(COLL == 0 || COLL == 1, "two-step kernel: streaming only or BGK");
-  __shared__ T lds[3][S::Q][NI];
+  __shared__ T lds_u[4][NU][NI];
+  __shared__ T lds_c[3][NC][NI];
+  __shared__ T lds_d[2][ND][NI];
 
   const int tid = threadIdx.x;
   const int tiles0 = p.n0 / T0, tiles1 = p.n1 / T1;
@@ -802,8 +815,7 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   const int j1 = tid / T0, j0 = tid - j1 * T0;
 
   // Addresses: the plane part is uniform (scalar registers, recomputed per plane), the in-plane
-  // part is a per-thread constant -- nine byte offsets for the nine (e0, e1) pairs of the lattice --
-  // so that a load is "scalar base + 32-bit vector offset" with no vector arithmetic in the loop.
+  // part is a per-thread constant -- nine byte offsets for the nine (e0, e1) pairs of the lattice.
   const int g0m = g0 == 0 ? p.n0 - 1 : g0 - 1, g0p = g0 == p.n0 - 1 ? 0 : g0 + 1;
   const int g1m = g1 == 0 ? p.n1 - 1 : g1 - 1, g1p = g1 == p.n1 - 1 ? 0 : g1 + 1;
   unsigned voff[3][3];                               // [e1 + 1][e0 + 1], bytes within a plane
@@ -833,23 +845,29 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
       });
     }
   };
-  auto compute_a = [&](int slot) {
+  // r = index of the plane relative to s - 1; r3 = r % 3
+  auto compute_a = [&](int r, int r3) {
     if (in_a) {
       if constexpr (COLL == 1) collide_bgk<T, S, LAYOUT, 1, 0>(pre, p.tau_inv);
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        lds[slot][q][tid] = pre[q][0];
+        constexpr int e2 = M::e(q, 2), rank = crossing_rank<S, LAYOUT, q>();
+        if constexpr (e2 > 0) lds_u[r & 3][rank][tid] = pre[q][0];
+        else if constexpr (e2 == 0) lds_c[r3][rank][tid] = pre[q][0];
+        else lds_d[r & 1][rank][tid] = pre[q][0];
       });
     }
   };
   T f[S::Q][1];
-  auto read_b = [&](int sm, int sc, int sp) {       // planes k-1, k, k+1
+  auto read_b = [&](int r, int r3) {                 // output plane with relative index r
     if (in_b) {
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1), e2 = M::e(q, 2);
-        const int slot = e2 == 0 ? sc : (e2 > 0 ? sm : sp);
-        f[q][0] = lds[slot][q][(j1 + 1 - e1) * H0 + (j0 + 1 - e0)];
+        constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1), e2 = M::e(q, 2), rank = crossing_rank<S, LAYOUT, q>();
+        const int at = (j1 + 1 - e1) * H0 + (j0 + 1 - e0);
+        if constexpr (e2 > 0) f[q][0] = lds_u[(r - 1) & 3][rank][at];
+        else if constexpr (e2 == 0) f[q][0] = lds_c[r3][rank][at];
+        else f[q][0] = lds_d[(r + 1) & 1][rank][at];
       });
     }
   };
@@ -868,27 +886,24 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
     }
   };
 
-  // intermediate planes s-1 .. s+seg_len are needed; three are resident at any time
+  // intermediate planes s-1 .. s+seg_len are needed (relative indices 0 .. seg_len+1)
   const int last = s + seg_len;
-  load_a(s - 1); compute_a(0);
-  load_a(s);     compute_a(1);
-  load_a(s + 1); compute_a(2);
+  load_a(s - 1); compute_a(0, 0);
+  load_a(s);     compute_a(1, 1);
+  load_a(s + 1); compute_a(2, 2);
   if (s + 2 <= last) load_a(s + 2);
-  int sm = 0, sc = 1, sp = 2;
+  int r = 1, r3 = 1;                                // output plane k has relative index k - s + 1
   for (int k = s; k < last; ++k) {
-    lds_barrier();                                  // intermediate plane k + 1 is complete
-    read_b(sm, sc, sp);
-    lds_barrier();                                  // everybody has read plane k - 1: its slot is free
-    // All global-memory instructions of a plane are issued together at its end, the loads first:
-    // the vmcnt waits in front of compute_a then only ever meet operations that had the whole of
-    // collide_b to complete (stores issued right before them would be waited for one by one).
+    lds_barrier();                                  // planes up to k + 1 complete; reads of k - 1 done
+    read_b(r, r3);
     collide_b();
     if (k + 2 <= last) {
-      compute_a(sm);                                // intermediate plane k + 2 replaces plane k - 1
-      if (k + 3 <= last) load_a(k + 3);             // lands during the next plane
+      compute_a(r + 2, r3 == 0 ? 2 : r3 - 1);       // (r + 2) % 3
+      if (k + 3 <= last) load_a(k + 3);
     }
     store_b(k);
-    const int t = sm; sm = sc; sc = sp; sp = t;
+    ++r;
+    r3 = r3 == 2 ? 0 : r3 + 1;
   }
 }
 
