@@ -167,6 +167,22 @@ int lt_slab_pack(lt_plan *plan, const void *f_dev, int64_t plane, int32_t direct
 int lt_slab_unpack(lt_plan *plan, void *f_dev, int64_t plane, int32_t direction, const void *buf_dev,
                    void *stream);
 
+/* Two-step slabs (ghost_planes = 2 in the plan).  lt_stream_collide_twice_planes is
+ * lt_stream_collide_twice for the output planes [begin, end) of a slab: it reads planes
+ * [begin - 2, end + 2), so begin >= 2 and end <= n2 - 2.  Before the launch the ghost planes must hold,
+ * on the lower side, the in-plane and upward populations of the neighbour's top plane (ghost plane 1)
+ * and the upward populations of the plane below that (ghost plane 0); mirrored on the upper side.
+ * lt_slab_pack_two_step gathers exactly that message for the neighbour beyond `side` (-1 lower,
+ * +1 upper) from this rank's two interior planes next to the cut, as
+ *   buf[n_in_plane + 2 n_crossing][n1*n0] = [in-plane of the near plane | crossing of the near
+ *   plane | crossing of the far plane]           (9 + 5 + 5 = 19 blocks for D3Q19);
+ * lt_slab_unpack_two_step scatters a received message into the two ghost planes beyond `side`.
+ * lt_slab_crossing(plan, 0, ...) reports the in-plane populations. */
+int lt_stream_collide_twice_planes(lt_plan *plan, const void *f_dev, void *out_dev, double tau,
+                                   int64_t begin, int64_t end, void *stream);
+int lt_slab_pack_two_step(lt_plan *plan, const void *f_dev, int32_t side, void *buf_dev, void *stream);
+int lt_slab_unpack_two_step(lt_plan *plan, void *f_dev, int32_t side, const void *buf_dev, void *stream);
+
 /* n whole lettuce steps (collide, boundaries, stream) starting from post-streaming
  * populations in buf_a (lettuce/_simulation.py:201-203): one collide launch, n-1 fused
  * launches, one stream launch, ping-ponging between the two buffers.  On return

@@ -91,6 +91,9 @@ SYMBOLS = {
     "lt_plan_set_residency": (ctypes.c_int, [_vp, _i32]),
     "lt_stream_collide_twice": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _vp]),
     "lt_plan_set_two_step": (ctypes.c_int, [_vp, _i32, _i32]),
+    "lt_stream_collide_twice_planes": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _i64, _vp]),
+    "lt_slab_pack_two_step": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
+    "lt_slab_unpack_two_step": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "lt_plan_set_fused_events": (ctypes.c_int, [_vp, _vp, _vp]),
     "lt_plan_last_run_info": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "lt_probe_copy": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
@@ -457,6 +460,19 @@ class Plan:
         self._check(self.lib.lt_stream_collide_twice(self._handle, _ptr(f), _ptr(out), float(tau),
                                                      _stream_handle()))
         return out
+
+    @_on_device
+    def stream_collide_twice_planes(self, f, out, tau, begin, end):
+        self._check(self.lib.lt_stream_collide_twice_planes(self._handle, _ptr(f), _ptr(out), float(tau),
+                                                            int(begin), int(end), _stream_handle()))
+
+    @_on_device
+    def pack_two_step(self, f, side, buf):
+        self._check(self.lib.lt_slab_pack_two_step(self._handle, _ptr(f), int(side), _ptr(buf), _stream_handle()))
+
+    @_on_device
+    def unpack_two_step(self, f, side, buf):
+        self._check(self.lib.lt_slab_unpack_two_step(self._handle, _ptr(f), int(side), _ptr(buf), _stream_handle()))
 
     def set_residency(self, workgroups_per_cu: int = -1):
         """-1 automatic, 0 no cap, 2..8 workgroups resident per CU for the chip-filling launches"""

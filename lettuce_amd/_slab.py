@@ -42,7 +42,7 @@ import torch.distributed as dist
 
 from .util import LettuceException
 
-__all__ = ["ZSlab", "SlabSimulation"]
+__all__ = ["ZSlab", "SlabSimulation", "TwoStepSlabSimulation"]
 
 
 class ZSlab:
@@ -151,6 +151,8 @@ class SlabSimulation:
     exchange with the gloo backend.
     """
 
+    GHOST = 1            # ghost planes per side
+
     def __init__(self, flow, collision, slab: ZSlab, reporter=None, engine=None, group=None,
                  overlap: bool = True, comm_priority: int = -1, transport: str = "rccl"):
         if list(flow.resolution) != slab.extended_resolution:
@@ -163,8 +165,9 @@ class SlabSimulation:
         self.i = 0
         self.overlap = overlap and self.context.device.type == "cuda"
         nx, ny, _ = slab.global_resolution
-        nzl, h = slab.nz_local, slab.halo
+        nzl, h, g = slab.nz_local, slab.halo, self.GHOST
         self.nzl = nzl
+        self.lo, self.hi = g, g + nzl               # interior planes [lo, hi) of the slab tensor
         self.up, self.down = _crossing_sets(flow.stencil)
         desc = collision.native_generator()
         self._tau = desc.tau
@@ -183,27 +186,27 @@ class SlabSimulation:
                                        "by the slab driver (use uniform velocity / pressure)")
             entries.append(entry)
         if ncm is not None:
-            ncm = ncm[..., h - 1:h + nzl + 1].permute(2, 1, 0).contiguous()
-            nsm = nsm[..., h - 1:h + nzl + 1].permute(0, 3, 2, 1).contiguous()
+            ncm = ncm[..., h - g:h + nzl + g].permute(2, 1, 0).contiguous()
+            nsm = nsm[..., h - g:h + nzl + g].permute(0, 3, 2, 1).contiguous()
         self.no_collision_mask, self.no_streaming_mask = ncm, nsm
         if engine is None:
             from ._native import Plan, LAYOUT_SLAB
             engine = Plan(type(flow.stencil).__name__, self.context.dtype, desc.kind,
-                          slab.local_resolution, entries, layout=LAYOUT_SLAB, ghost_planes=1,
+                          slab.local_resolution, entries, layout=LAYOUT_SLAB, ghost_planes=g,
                           device=self.context.device)
             if ncm is not None:
                 engine.set_masks(ncm, nsm)
         elif entries:
             engine.set_boundaries(entries, ncm, nsm, flow.units)      # test stand-ins
         self.engine = engine
-        # [q, nx, ny, nzl + 2] incl. one ghost plane per side -> [q, nzl + 2, ny, nx]
-        core = flow.f[..., h - 1:h + nzl + 1]
+        # [q, nx, ny, nzl + 2g] incl. the ghost planes -> [q, nzl + 2g, ny, nx]
+        core = flow.f[..., h - g:h + nzl + g]
         self.f = core.permute(0, 3, 2, 1).contiguous()
         self.f_next = torch.empty_like(self.f)
         flow.f = None                       # the extended slab is not needed any more
         flow._f_next = None
         # one contiguous message per direction: [n_crossing, ny, nx]
-        shape = [len(self.up), ny, nx]
+        shape = [self._message_blocks(flow.stencil), ny, nx]
         new = lambda: torch.empty(shape, dtype=self.f.dtype, device=self.f.device)   # noqa: E731
         self._send_up, self._send_down, self._recv_up, self._recv_down = new(), new(), new(), new()
         self._comm = (torch.cuda.Stream(device=self.context.device, priority=comm_priority)
@@ -224,10 +227,13 @@ class SlabSimulation:
                                        "process group")
             self._window = _PeerWindow(shape, self.f.dtype, self.f.device, slab, group)
 
+    def _message_blocks(self, stencil) -> int:
+        return len(self.up)
+
     # ---- views ---------------------------------------------------------------------------------
     def local_f(self) -> torch.Tensor:
         """this rank's populations as a ``[q, nx, ny, nz_local]`` view (reference axis order)"""
-        return self.f[:, 1:self.nzl + 1].permute(0, 3, 2, 1)
+        return self.f[:, self.lo:self.hi].permute(0, 3, 2, 1)
 
     def gather_f(self, dst: int = 0) -> Optional[torch.Tensor]:
         """global ``[q, nx, ny, nz]`` tensor on rank ``dst`` (small grids / tests only)"""
@@ -396,3 +402,109 @@ class SlabSimulation:
             dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
         dx = units.convert_length_to_pu(1.0)
         return float(units.convert_incompressible_energy_to_pu(total) * dx ** 3)
+
+
+class TwoStepSlabSimulation(SlabSimulation):
+    """Slab driver for the two-step kernel (``lt_stream_collide_twice_planes``): two lattice updates
+    per launch and ONE halo exchange per two updates.  Periodic flows without boundaries; the
+    engine decides which lattices / dtypes / grids it supports (D3Q19 fp32, nx % 64 == 0,
+    ny % 8 == 0 at present) and raises otherwise.
+
+    Two ghost planes per side.  Before a two-step launch the lower ghost planes must hold the
+    in-plane and upward populations of the lower neighbour's top plane and the upward populations
+    of the plane below it (mirrored above): 9 + 5 + 5 = 19 plane-populations per direction for
+    D3Q19 instead of 2 x 5 for two single steps, in half as many messages.
+
+    Schedule of one double step: the communication stream computes the two output planes next to
+    each cut (two small launches), packs, transfers and unpacks; the compute stream does the
+    interior output planes meanwhile; the streams join before the next launch.
+    """
+
+    GHOST = 2
+
+    def __init__(self, flow, collision, slab: ZSlab, **kwargs):
+        if flow.boundaries:
+            raise LettuceException("the two-step slab driver handles periodic flows only")
+        if slab.nz_local < 4:
+            raise LettuceException("the two-step slab driver needs at least 4 planes per rank")
+        super().__init__(flow, collision, slab, **kwargs)
+
+    def _message_blocks(self, stencil) -> int:
+        e = np.array(stencil.e)
+        return int((e[:, 2] == 0).sum()) + 2 * len(self.up)
+
+    # ---- halo exchange -------------------------------------------------------------------------
+    def _exchange(self, buf: torch.Tensor, packed: bool = False):
+        """Fill the four ghost planes of ``buf`` (post-collision populations).  My message for the
+        lower neighbour comes from my two lowest interior planes and lands in its upper ghost
+        planes, and vice versa."""
+        eng, s = self.engine, self.slab
+        if self._window is not None:
+            to_prev, to_next = self._window.targets()
+            eng.pack_two_step(buf, -1, to_prev)
+            eng.pack_two_step(buf, +1, to_next)
+            from_above, from_below = self._window.signal_and_wait()
+
+            def finish_window():
+                eng.unpack_two_step(buf, +1, from_above)
+                eng.unpack_two_step(buf, -1, from_below)
+            return finish_window
+        eng.pack_two_step(buf, -1, self._send_down)
+        eng.pack_two_step(buf, +1, self._send_up)
+        if s.world_size == 1 and not self._force_p2p:
+            from_above, from_below, reqs = self._send_down, self._send_up, []
+        else:
+            from_above, from_below = self._recv_down, self._recv_up
+            if self._host_transport and buf.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            ops = [dist.P2POp(dist.isend, self._send_down, s.prev, self.group, tag=1),
+                   dist.P2POp(dist.irecv, from_above, s.next, self.group, tag=1),
+                   dist.P2POp(dist.isend, self._send_up, s.next, self.group, tag=2),
+                   dist.P2POp(dist.irecv, from_below, s.prev, self.group, tag=2)]
+            reqs = dist.batch_isend_irecv(ops)
+
+        def finish():
+            for r in reqs:
+                r.wait()
+            if reqs and self._host_transport and buf.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            eng.unpack_two_step(buf, +1, from_above)
+            eng.unpack_two_step(buf, -1, from_below)
+        return finish
+
+    # ---- stepping --------------------------------------------------------------------------------
+    def _double_step(self, cur, nxt, tau):
+        eng, lo, hi = self.engine, self.lo, self.hi
+        if self.overlap and hi - lo >= 8:
+            compute = torch.cuda.current_stream()
+            self._comm.wait_stream(compute)
+            with torch.cuda.stream(self._comm):
+                eng.stream_collide_twice_planes(cur, nxt, tau, lo, lo + 2)
+                eng.stream_collide_twice_planes(cur, nxt, tau, hi - 2, hi)
+                self._exchange(nxt)()
+            eng.stream_collide_twice_planes(cur, nxt, tau, lo + 2, hi - 2)
+            compute.wait_stream(self._comm)
+        else:
+            eng.stream_collide_twice_planes(cur, nxt, tau, lo, hi)
+            self._exchange(nxt)()
+
+    def _advance(self, n: int):
+        """n whole steps: collide, exchange, floor((n-1)/2) double steps (+ one single fused step
+        when n-1 is odd), stream."""
+        tau = float(self._tau(self.flow))
+        eng, lo, hi = self.engine, self.lo, self.hi
+        cur, nxt = self.f, self.f_next
+        eng.collide_planes(cur, nxt, tau, lo, hi)
+        cur, nxt = nxt, cur
+        self._exchange(cur)()
+        fused = n - 1
+        while fused >= 2:
+            self._double_step(cur, nxt, tau)
+            cur, nxt = nxt, cur
+            fused -= 2
+        if fused == 1:
+            eng.stream_collide_planes(cur, nxt, tau, lo, hi)
+            cur, nxt = nxt, cur
+            self._exchange(cur)()
+        eng.stream_planes(cur, nxt, lo, hi)
+        self.f, self.f_next = nxt, cur

@@ -232,20 +232,59 @@ int resolve_lds(const lt_plan *p, long long workgroups) {
 // planes.  Pick the divisor L of n2 with the best (L / (L + 2)) * (blocks / blocks rounded up to
 // whole rounds): 128 planes = 256 workgroups at 256^3 (measured 0.3345 ms per step against 0.3412
 // with 32 planes and 0.52 with 256, which leaves half the CUs idle).
-int resolve_seg_len(const lt_plan *p) {
+int resolve_seg_len(const lt_plan *p, int planes) {
   if (p->seg_len > 0) return p->seg_len;
   const long long tiles = (long long)(p->n0 / 64) * (p->n1 / 8);
   const long long cus = p->n_cu > 0 ? p->n_cu : 256;
   int best = 1;
   double best_score = -1.0;
-  for (int len = 1; len <= p->n2; ++len) {
-    if (p->n2 % len) continue;
-    const long long blocks = tiles * (p->n2 / len);
+  for (int len = 1; len <= planes; ++len) {
+    const long long segs = (planes + len - 1) / len;
+    if (!p->desc.ghost_planes && planes % len) continue;   // keep whole-grid launches evenly cut
+    const long long blocks = tiles * segs;
     const long long rounds = (blocks + cus - 1) / cus;
-    const double score = ((double)len / (len + 2)) * ((double)blocks / (double)(rounds * cus));
+    const double score = ((double)planes / (double)(planes + 2 * segs)) *
+                         ((double)blocks / (double)(rounds * cus));
     if (score > best_score) { best_score = score; best = len; }
   }
   return best;
+}
+
+// Two-step slab halo: side -1 = lower cut, +1 = upper cut.  Packing reads the two interior planes
+// next to the cut, unpacking fills the two ghost planes beyond it.
+int halo2(lt_plan *p, bool do_pack, void *f, int side, void *buf, void *stream) {
+  if (!p || !f || !buf) return fail(LT_ERR_INVALID, "null argument");
+  if (side != 1 && side != -1) return fail(LT_ERR_INVALID, "side %d (must be +1 or -1)", side);
+  if (p->desc.ghost_planes != 2) return fail(LT_ERR_INVALID, "the two-step halo needs ghost_planes = 2");
+  const int g = 2, n2 = p->n2;
+  long long near, far;
+  int dir;
+  if (do_pack) {     // what the neighbour beyond `side` needs: populations staying in / leaving through the cut
+    near = side < 0 ? g : n2 - g - 1;
+    far = side < 0 ? g + 1 : n2 - g - 2;
+    dir = side;
+  } else {           // what arrived from the neighbour beyond `side`: populations entering through the cut
+    near = side < 0 ? g - 1 : n2 - g;
+    far = side < 0 ? g - 2 : n2 - g + 1;
+    dir = -side;
+  }
+  const lt::QList in_plane = crossing(p, 0), cross = crossing(p, dir);
+  const int plane_nodes = p->n0 * p->n1;
+  const unsigned grid = (plane_nodes + lt::kThreads - 1) / lt::kThreads;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (p->desc.dtype == LT_F32) {
+    if (do_pack) hipLaunchKernelGGL((lt::halo2_kernel<float, true>), dim3(grid), dim3(lt::kThreads), 0, s, (float *)f,
+                                    (float *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross);
+    else hipLaunchKernelGGL((lt::halo2_kernel<float, false>), dim3(grid), dim3(lt::kThreads), 0, s, (float *)f,
+                            (float *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross);
+  } else {
+    if (do_pack) hipLaunchKernelGGL((lt::halo2_kernel<double, true>), dim3(grid), dim3(lt::kThreads), 0, s, (double *)f,
+                                    (double *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross);
+    else hipLaunchKernelGGL((lt::halo2_kernel<double, false>), dim3(grid), dim3(lt::kThreads), 0, s, (double *)f,
+                            (double *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross);
+  }
+  LT_HIP(hipGetLastError());
+  return LT_OK;
 }
 
 int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long pb, long long pe,
@@ -258,6 +297,16 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   if (p->desc.ghost_planes && (pb < 1 || pe > p->n2 - 1) && mode != lt::kCollideOnly && pe > pb)
     return fail(LT_ERR_INVALID, "streaming from ghost planes: range [%lld, %lld) must stay in [1, %d)",
                 pb, pe, p->n2 - 1);
+  if (mode == lt::kFusedTwice) {
+    if (p->desc.ghost_planes == 1)
+      return fail(LT_ERR_INVALID, "two steps per launch read two planes beyond the range: the plan needs "
+                                  "ghost_planes = 2");
+    if (p->desc.ghost_planes == 2 && (pb < 2 || pe > p->n2 - 2) && pe > pb)
+      return fail(LT_ERR_INVALID, "two-step range [%lld, %lld) must stay in [2, %d)", pb, pe, p->n2 - 2);
+    if (!p->desc.ghost_planes && (pb != 0 || pe != p->n2))
+      return fail(LT_ERR_INVALID, "periodic plan: the two-step launch covers all planes");
+    if (p->masked) return fail(LT_ERR_UNSUPPORTED, "two steps per launch: no masks / boundaries");
+  }
   if (p->desc.n_boundaries > 0 && !p->masked)
     return fail(LT_ERR_INVALID, "plan has boundaries but lt_plan_set_masks was not called");
   if (mode != lt::kStreamOnly && p->desc.collision != LT_COLLISION_NONE && !(tau > 0.0))
@@ -278,7 +327,7 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.shift = a.wide ? p->shift : 0;
   a.tune = resolve_tune(p, a.wide);
   a.lds_bytes = resolve_lds(p, ((long long)a.planes * a.n1 * a.n0 + 255) / 256);
-  a.seg_len = mode == lt::kFusedTwice ? resolve_seg_len(p) : 0;
+  a.seg_len = mode == lt::kFusedTwice ? resolve_seg_len(p, a.planes) : 0;
   if (mode == lt::kFusedTwice) a.shift = p->shift;      // tile-shape A/B variant
   a.stream = static_cast<hipStream_t>(stream);
   a.pack_lo = pack_lo; a.pack_hi = pack_hi;
@@ -451,8 +500,9 @@ int lt_plan_create(const lt_plan_desc *d, lt_plan **out) {
   if (d->layout != LT_LAYOUT_REFERENCE && d->layout != LT_LAYOUT_SLAB)
     return fail(LT_ERR_INVALID, "layout %d", d->layout);
   if (d->layout == LT_LAYOUT_SLAB && unit.d != 3) return fail(LT_ERR_UNSUPPORTED, "slab layout is 3-D only");
-  if (d->ghost_planes != 0 && !(d->ghost_planes == 1 && d->layout == LT_LAYOUT_SLAB))
-    return fail(LT_ERR_INVALID, "ghost_planes = %d needs the slab layout", d->ghost_planes);
+  if (d->ghost_planes != 0 &&
+      !((d->ghost_planes == 1 || d->ghost_planes == 2) && d->layout == LT_LAYOUT_SLAB))
+    return fail(LT_ERR_INVALID, "ghost_planes = %d (0, or 1 / 2 with the slab layout)", d->ghost_planes);
   if (d->n_boundaries < 0 || d->n_boundaries > LT_MAX_BOUNDARIES)
     return fail(LT_ERR_UNSUPPORTED, "%d boundaries (max %d)", d->n_boundaries, LT_MAX_BOUNDARIES);
   for (int a = 0; a < unit.d; ++a)
@@ -691,7 +741,19 @@ int lt_plan_set_graph_mode(lt_plan *p, int32_t mode) {
 
 int lt_stream_collide_twice(lt_plan *p, const void *f, void *out, double tau, void *stream) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
-  return step(p, lt::kFusedTwice, f, out, tau, 0, p->n2, stream);
+  const int g = p->desc.ghost_planes;
+  return step(p, lt::kFusedTwice, f, out, tau, g, p->n2 - g, stream);
+}
+int lt_stream_collide_twice_planes(lt_plan *p, const void *f, void *out, double tau, int64_t begin,
+                                   int64_t end, void *stream) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  return step(p, lt::kFusedTwice, f, out, tau, begin, end, stream);
+}
+int lt_slab_pack_two_step(lt_plan *p, const void *f, int32_t side, void *buf, void *s) {
+  return halo2(p, true, const_cast<void *>(f), side, buf, s);
+}
+int lt_slab_unpack_two_step(lt_plan *p, void *f, int32_t side, const void *buf, void *s) {
+  return halo2(p, false, f, side, const_cast<void *>(buf), s);
 }
 
 int lt_plan_set_fused_events(lt_plan *p, void *start_event, void *stop_event) {
@@ -713,7 +775,8 @@ int lt_plan_last_run_info(lt_plan *p, int64_t *single_step_launches, int64_t *tw
 int lt_plan_set_two_step(lt_plan *p, int32_t mode, int32_t planes_per_workgroup) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (mode < -1 || mode > 1) return fail(LT_ERR_INVALID, "two-step mode %d", mode);
-  if (planes_per_workgroup < 0 || (planes_per_workgroup > 0 && p->n2 % planes_per_workgroup != 0))
+  if (planes_per_workgroup < 0 ||
+      (planes_per_workgroup > 0 && !p->desc.ghost_planes && p->n2 % planes_per_workgroup != 0))
     return fail(LT_ERR_INVALID, "planes per workgroup %d does not divide %d", planes_per_workgroup, p->n2);
   p->two_step = mode;
   p->seg_len = planes_per_workgroup;

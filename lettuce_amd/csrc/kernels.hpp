@@ -53,6 +53,7 @@ struct KParams {
   int n0, n1, n2;            // memory extents; n2 includes ghost planes
   int nv0;                   // n0 / VEC
   int p_begin;               // first a2 plane of this launch
+  int p_end;                 // two-step kernel: one past the last output plane
   int p_stride;              // distance between consecutive planes of this launch (normally 1)
   int wrap2;                 // periodic wrap along a2 (0 with ghost planes)
   long long N;               // n0*n1*n2 = stride between populations
@@ -803,7 +804,7 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   if (p.nb == 0 && gridDim.x % 8 == 0) b = (b % 8) * (gridDim.x / 8) + b / 8;
   const int t0 = (b % tiles0) * T0; b /= tiles0;
   const int t1 = (b % tiles1) * T1; b /= tiles1;
-  const int s = b * seg_len;                       // first output plane of this workgroup
+  const int s = p.p_begin + b * seg_len;           // first output plane of this workgroup
 
   // phase A: node (i0, i1) of the halo'd tile, global coordinates (g0, g1)
   const bool in_a = tid < NI;
@@ -832,8 +833,13 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
 
   T pre[S::Q][1];
   auto load_a = [&](int plane) {
-    const int g2 = plane < 0 ? plane + p.n2 : (plane >= p.n2 ? plane - p.n2 : plane);
-    const int g2m = g2 == 0 ? p.n2 - 1 : g2 - 1, g2p = g2 == p.n2 - 1 ? 0 : g2 + 1;
+    // periodic along a2, or a slab whose ghost planes (two per side) hold the neighbours' data
+    int g2 = plane, g2m = plane - 1, g2p = plane + 1;
+    if (p.wrap2) {
+      g2 = plane < 0 ? plane + p.n2 : (plane >= p.n2 ? plane - p.n2 : plane);
+      g2m = g2 == 0 ? p.n2 - 1 : g2 - 1;
+      g2p = g2 == p.n2 - 1 ? 0 : g2 + 1;
+    }
     if (in_a) {
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
@@ -887,7 +893,7 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   };
 
   // intermediate planes s-1 .. s+seg_len are needed (relative indices 0 .. seg_len+1)
-  const int last = s + seg_len;
+  const int last = s + seg_len < p.p_end ? s + seg_len : p.p_end;
   load_a(s - 1); compute_a(0, 0);
   load_a(s);     compute_a(1, 1);
   load_a(s + 1); compute_a(2, 2);
@@ -1031,6 +1037,30 @@ __global__ void __launch_bounds__(kThreads) plane_pack_kernel(T *__restrict__ f,
       T *slot = f + (long long)ql.q[k] * N + plane_off + i;
       if (PACK) buf[(long long)k * plane_nodes + i] = *slot;
       else *slot = buf[(long long)k * plane_nodes + i];
+    }
+  }
+}
+
+// Halo message of the two-step slab driver: [in-plane populations of the plane next to the cut |
+// crossing populations of that plane | crossing populations of the plane behind it], each a
+// contiguous block of plane_nodes values.  PACK: f -> buf, else buf -> f.
+template <typename T, bool PACK>
+__global__ void __launch_bounds__(kThreads) halo2_kernel(T *__restrict__ f, T *__restrict__ buf, long long N,
+                                                         long long off_near, long long off_far,
+                                                         int plane_nodes, QList in_plane, QList cross) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= plane_nodes) return;
+  auto move = [&](int slot, int q, long long off) {
+    T *at = f + (long long)q * N + off + i;
+    if (PACK) buf[(long long)slot * plane_nodes + i] = *at;
+    else *at = buf[(long long)slot * plane_nodes + i];
+  };
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    if (k < in_plane.n) move(k, in_plane.q[k], off_near);
+    if (k < cross.n) {
+      move(in_plane.n + k, cross.q[k], off_near);
+      move(in_plane.n + cross.n + k, cross.q[k], off_far);
     }
   }
 }

@@ -74,3 +74,29 @@ class OracleSlabEngine:
 
     def stream_collide_planes(self, f, out, tau, b, e):
         out[:, b:e] = self._collide_and_boundaries(self._stream(f, b, e), tau, b, e)
+
+    # ---- two-step slabs (two ghost planes per side) -------------------------------------------
+    def stream_collide_twice_planes(self, f, out, tau, b, e):
+        tmp = f.clone()
+        self.stream_collide_planes(f, tmp, tau, b - 1, e + 1)
+        self.stream_collide_planes(tmp, out, tau, b, e)
+
+    def _sets(self, direction):
+        ez = [v[2] for v in self.lat.e]
+        return ([q for q in range(self.lat.q) if ez[q] == 0],
+                [q for q in range(self.lat.q) if ez[q] == direction])
+
+    def pack_two_step(self, f, side, buf):
+        n2 = f.shape[1]
+        near, far = (2, 3) if side < 0 else (n2 - 3, n2 - 4)
+        in_plane, cross = self._sets(side)
+        buf.copy_(torch.cat([f[in_plane, near], f[cross, near], f[cross, far]]))
+
+    def unpack_two_step(self, f, side, buf):
+        n2 = f.shape[1]
+        near, far = (1, 0) if side < 0 else (n2 - 2, n2 - 1)
+        in_plane, cross = self._sets(-side)
+        a, b = len(in_plane), len(cross)
+        f[in_plane, near] = buf[:a]
+        f[cross, near] = buf[a:a + b]
+        f[cross, far] = buf[a + b:]

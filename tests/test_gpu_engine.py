@@ -510,3 +510,33 @@ def test_two_step_unsupported_combinations_fail_loudly():
         plan.set_two_step(1)
         plan.run(f, torch.empty_like(f), 0.6, 4)
         assert plan.last_run_info()["two_step_launches"] == 0
+
+
+def test_two_step_on_a_slab_with_two_ghost_planes_equals_two_single_steps():
+    """lt_stream_collide_twice_planes on a slab-layout plan (no wrap along z, ragged last segment) and
+    the two-step halo pack / unpack pair."""
+    from lettuce_amd._native import Plan, LAYOUT_SLAB
+    res = [64, 16, 10]                                   # local slab: nx, ny, nz
+    plan = Plan("D3Q19", torch.float32, "bgk", res, [], layout=LAYOUT_SLAB, ghost_planes=2)
+    plan.set_two_step(1, 4)                              # 10 planes in segments of 4, 4, 2
+    torch.manual_seed(11)
+    f = (0.05 + 0.01 * torch.rand(plan.f_shape, device="cuda")).contiguous()
+    a, b, c = torch.zeros_like(f), torch.zeros_like(f), torch.zeros_like(f)
+    n2 = f.shape[1]
+    plan.stream_collide_planes(f, a, 0.6, 1, n2 - 1)
+    plan.stream_collide_planes(a, b, 0.6, 2, n2 - 2)
+    plan.stream_collide_twice_planes(f, c, 0.6, 2, n2 - 2)
+    assert torch.equal(b[:, 2:n2 - 2], c[:, 2:n2 - 2])
+    plan.stream_collide_twice_planes(f, c, 0.6, 3, 6)    # a sub-range
+    assert torch.equal(b[:, 3:6], c[:, 3:6])
+    # halo message: 9 in-plane + 5 + 5 crossing blocks; unpack(pack) moves interior planes to ghosts
+    msg = torch.empty([19, 16, 64], device="cuda")
+    g = f.clone()
+    plan.pack_two_step(f, -1, msg)                       # my lower planes 2, 3 ...
+    plan.unpack_two_step(g, +1, msg)                     # ... become the upper ghosts of the rank below
+    e = np.array(orc.LATTICES["D3Q19"].e)
+    inp, down = np.nonzero(e[:, 2] == 0)[0], np.nonzero(e[:, 2] == -1)[0]
+    assert torch.equal(g[inp, n2 - 2], f[inp, 2]) and torch.equal(g[down, n2 - 2], f[down, 2])
+    assert torch.equal(g[down, n2 - 1], f[down, 3])
+    up = np.nonzero(e[:, 2] == 1)[0]
+    assert torch.equal(g[up, n2 - 2], f[up, n2 - 2])      # untouched

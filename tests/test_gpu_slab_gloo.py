@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, res, steps, dtype_name, overlap, out_dir):
+def _worker(rank, world, port, res, steps, dtype_name, overlap, out_dir, driver="SlabSimulation"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -25,8 +25,8 @@ def _worker(rank, world, port, res, steps, dtype_name, overlap, out_dir):
     ctx = lt.Context("cuda:0", getattr(torch, dtype_name), use_native=True)
     slab = lt.ZSlab(res)
     flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 400, 0.1, lt.D3Q19(), slab=slab)
-    sim = lt.SlabSimulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
-                            overlap=overlap)
+    sim = getattr(lt, driver)(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
+                              overlap=overlap)
     sim(steps)
     f1 = sim.gather_f()
     ke = sim.kinetic_energy_pu()
@@ -49,6 +49,53 @@ def test_ranks_sharing_one_gpu(tmp_path, world, overlap):
     ref.step(steps)
     np.testing.assert_allclose(got["f1"], ref.f.numpy(), rtol=0, atol=1e-13)
     assert float(got["ke"]) == pytest.approx(float(orc.kinetic_energy_pu(ref.f, ref.lat, ref.units)), rel=1e-11)
+
+
+@pytest.mark.parametrize("world,overlap,steps", [(2, True, 7), (2, False, 6), (3, True, 4)],
+                         ids=["2ranks-overlap-7steps", "2ranks-serial-6steps", "3ranks-overlap-4steps"])
+def test_two_step_slab_ranks_sharing_one_gpu(tmp_path, world, overlap, steps):
+    """TwoStepSlabSimulation with the real kernels (lt_stream_collide_twice_planes on slabs with two
+    ghost planes, lt_slab_pack/unpack_two_step) on 2-3 gloo ranks sharing the GPU, fp32, against the
+    single-domain oracle; boundary / interior launches on two streams when overlapping."""
+    from oracle import lettuce_oracle as orc
+    res = [64, 16, 12 * world]
+    port = 29600 + (os.getpid() % 1000) + int(overlap) + 10 * world
+    mp.spawn(_worker, args=(world, port, res, steps, "float32", overlap, str(tmp_path), "TwoStepSlabSimulation"),
+             nprocs=world, join=True)
+    got = np.load(tmp_path / "out.npz")
+    ref = orc.taylor_green(res, 400, 0.1, "D3Q19", torch.float32)
+    ref.step(steps)
+    np.testing.assert_allclose(got["f1"], ref.f.numpy(), rtol=0, atol=1e-5 * float(np.abs(ref.f.numpy()).max()))
+
+
+def _two_step_identity_worker(rank, port, res, steps, transport, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if transport == "rccl":
+        os.environ["LT_SLAB_FORCE_P2P"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    import lettuce_amd as lt
+    ctx = lt.Context("cuda:0", torch.float32, use_native=True)
+    outs = []
+    for driver in ("SlabSimulation", "TwoStepSlabSimulation"):
+        slab = lt.ZSlab(res)
+        flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 400, 0.1, lt.D3Q19(), slab=slab)
+        sim = getattr(lt, driver)(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
+                                  transport=transport)
+        sim(steps)
+        outs.append(sim.gather_f().clone())
+    np.savez(os.path.join(out_dir, "out.npz"), same=bool(torch.equal(outs[0], outs[1])))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("transport", ["rccl", "window"])
+def test_two_step_slab_is_bit_identical_to_the_single_step_slab(tmp_path, transport):
+    """Same kernels' arithmetic, different schedule and halo: the two drivers must agree bit for bit
+    (single rank exchanging with itself through RCCL / through its own peer window)."""
+    mp.spawn(_two_step_identity_worker, args=(29950 + os.getpid() % 1000, [64, 32, 16], 9, transport, str(tmp_path)),
+             nprocs=1, join=True)
+    assert bool(np.load(tmp_path / "out.npz")["same"])
 
 
 def _rccl_worker(rank, port, res, steps, out_dir):

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def _worker(rank, world, port, res, lattice, collision, steps, dtype_name, out_dir):
+def _worker(rank, world, port, res, lattice, collision, steps, dtype_name, out_dir, driver="SlabSimulation"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
@@ -29,7 +29,7 @@ def _worker(rank, world, port, res, lattice, collision, steps, dtype_name, out_d
     flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 400, 0.1, stencil, slab=slab)
     coll = lt.BGKCollision(flow.units.relaxation_parameter_lu) if collision == "bgk" else lt.KBCCollision()
     engine = OracleSlabEngine(lattice, dtype, collision)
-    sim = lt.SlabSimulation(flow, coll, slab, engine=engine)
+    sim = getattr(lt, driver)(flow, coll, slab, engine=engine)
     f0 = sim.gather_f()
     sim(steps)
     f1 = sim.gather_f()
@@ -63,6 +63,41 @@ def test_slab_ranks_reproduce_single_domain(tmp_path, world, res, lattice, colli
     np.testing.assert_allclose(got["f1"], ref.f.numpy(), rtol=0, atol=tol)
     ke_ref = float(orc.kinetic_energy_pu(ref.f, ref.lat, ref.units))
     assert float(got["ke"]) == pytest.approx(ke_ref, rel=1e-12 if dtype_name == "float64" else 1e-5)
+
+
+TWO_STEP_CASES = [(2, [8, 6, 16], 6), (2, [8, 6, 16], 5), (4, [8, 6, 16], 4), (3, [6, 4, 12], 7)]
+
+
+@pytest.mark.parametrize("world,res,steps", TWO_STEP_CASES, ids=[f"{c[0]}ranks-{c[2]}steps" for c in TWO_STEP_CASES])
+def test_two_step_slab_ranks_reproduce_single_domain(tmp_path, world, res, steps):
+    """The two-step slab driver (two ghost planes, one 19-block message per direction per double
+    step, odd and even numbers of fused steps) on 2-4 gloo ranks against the single-domain oracle."""
+    from oracle import lettuce_oracle as orc
+    port = 29100 + (os.getpid() % 2000) + world + steps
+    mp.spawn(_worker, args=(world, port, res, "D3Q19", "bgk", steps, "float64", str(tmp_path),
+                            "TwoStepSlabSimulation"), nprocs=world, join=True)
+    got = np.load(tmp_path / "out.npz")
+    ref = orc.taylor_green(res, 400, 0.1, "D3Q19", torch.float64, "bgk")
+    np.testing.assert_allclose(got["f0"], ref.f.numpy(), rtol=0, atol=2e-15)
+    ref.step(steps)
+    np.testing.assert_allclose(got["f1"], ref.f.numpy(), rtol=0, atol=1e-13)
+    assert float(got["ke"]) == pytest.approx(float(orc.kinetic_energy_pu(ref.f, ref.lat, ref.units)), rel=1e-12)
+
+
+def test_two_step_slab_single_rank_and_batches():
+    import lettuce_amd as lt
+    from slab_cpu_engine import OracleSlabEngine
+    from oracle import lettuce_oracle as orc
+    res = [6, 4, 5]
+    ctx = lt.Context("cpu", torch.float64, use_native=False)
+    slab = lt.ZSlab(res, rank=0, world_size=1)
+    flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 100, 0.1, lt.D3Q19(), slab=slab)
+    sim = lt.TwoStepSlabSimulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
+                                   engine=OracleSlabEngine("D3Q19", torch.float64, "bgk"))
+    ref = orc.taylor_green(res, 100, 0.1, "D3Q19", torch.float64)
+    sim(1); sim(2); sim(3); sim(4)
+    ref.step(10)
+    np.testing.assert_allclose(sim.gather_f().numpy(), ref.f.numpy(), rtol=0, atol=1e-13)
 
 
 def test_single_rank_slab_self_exchange():
