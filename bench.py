@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--transport", choices=["auto", "rccl", "window"], default="auto",
                     help="slab path: ghost-plane transport (lettuce_amd/_slab.py); auto = run the "
                          "warm-up with both, require bit-identical populations, keep the faster")
+    ap.add_argument("--driver", choices=["auto", "single-step", "two-step"], default="auto",
+                    help="slab path: restrict the candidates to one slab driver")
     ap.add_argument("--slab", action="store_true",
                     help="use the z-slab driver (and an RCCL process group) even with one GPU: "
                          "rehearsal of the N > 1 code path")
@@ -181,48 +183,58 @@ def main():
             global_res = [n, n, n * world]
         slab = lt.ZSlab(global_res)
 
-        def build(transport):
+        def build(driver, transport):
             flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 1600, 0.1, lt.D3Q19(), slab=slab)
-            return lt.SlabSimulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
-                                     overlap=not args.no_overlap, transport=transport)
+            cls = lt.TwoStepSlabSimulation if driver == "two-step" else lt.SlabSimulation
+            return cls(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
+                       overlap=not args.no_overlap, transport=transport)
 
         def all_ranks(flag: bool) -> bool:
             t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return bool(t.item())
 
-        # candidates: the RCCL transport always; the one-sided window transport unless excluded.
-        # Each does 3 + W warm-up steps from the same initial state (the W timed, max over ranks); the
-        # window transport is only eligible when its populations are bit-identical to RCCL's.
-        wanted = ["rccl", "window"] if args.transport == "auto" else [args.transport]
-        sims, probe = {}, {}
-        for name in wanted:
-            if name == "window":
-                # preflight on every rank before the collective rendezvous inside build(): a rank
-                # that cannot allocate peer-mappable memory must not leave the others waiting
-                try:
-                    import torch.distributed._symmetric_memory as symm
-                    symm.empty(1024, dtype=torch.float32, device=device)
-                    ok = True
-                except Exception as exc:
-                    ok = False
-                    probe[name] = f"unavailable: {type(exc).__name__}: {str(exc)[:120]}"
-                if not all_ranks(ok):
-                    probe.setdefault(name, "unavailable on another rank")
+        # Candidates: slab driver (two lattice updates per launch and one halo exchange per two
+        # updates / one update per launch) x transport (RCCL send/recv / one-sided peer windows).
+        # The single-step driver over RCCL is the reference: every candidate does 3 + W warm-up
+        # steps from the same initial state (the W timed, max over ranks), must end with populations
+        # bit-identical to the reference's on every rank, and the fastest eligible one runs the
+        # timed K steps.  All warm-up rates go into the JSON line.
+        transports = ["rccl", "window"] if args.transport == "auto" else [args.transport]
+        drivers = ["two-step", "single-step"] if args.driver == "auto" else [args.driver]
+        wanted = [(d, t) for d in drivers for t in transports]
+        if args.driver == "auto" and args.transport == "auto":
+            wanted = [("single-step", "rccl")] + [w for w in wanted if w != ("single-step", "rccl")]
+        finals, probe = {}, {}
+        window_ok = None
+        for driver, transport in wanted:
+            name = f"{driver}/{transport}"
+            if transport == "window":
+                if window_ok is None:
+                    # preflight on every rank before the collective rendezvous inside build(): a rank
+                    # that cannot allocate peer-mappable memory must not leave the others waiting
+                    try:
+                        import torch.distributed._symmetric_memory as symm
+                        symm.empty(1024, dtype=torch.float32, device=device)
+                        ok = True
+                    except Exception as exc:
+                        ok = False
+                        probe[name] = f"unavailable: {type(exc).__name__}: {str(exc)[:120]}"
+                    window_ok = all_ranks(ok)
+                if not window_ok:
+                    probe.setdefault(name, "unavailable: no peer-mappable memory on some rank")
                     continue
             try:
-                sims[name] = build(name)
+                cand = build(driver, transport)
+                cand(3)                         # connection set-up, first launches: not timed
                 ok = True
-            except Exception as exc:            # e.g. symmetric memory unavailable on this node
-                ok = False
+            except Exception as exc:            # unsupported grid for the two-step kernel, no symmetric memory ...
+                cand, ok = None, False
                 probe[name] = f"unavailable: {type(exc).__name__}: {str(exc)[:120]}"
             if not all_ranks(ok):
-                sims.pop(name, None)
                 probe.setdefault(name, "unavailable on another rank")
-        if not sims:
-            raise SystemExit(f"no usable slab transport: {probe}")
-        for name, cand in sims.items():
-            cand(3)                             # connection set-up, first launches: not timed
+                cand = None
+                continue
             barrier()
             t0 = time.perf_counter()
             cand(max(args.warmup, 1))
@@ -230,24 +242,37 @@ def main():
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             probe[name] = round(float(t.item()) / max(args.warmup, 1) * 1e3, 5)
-        check = None
-        if len(sims) == 2:
-            same = all_ranks(torch.equal(sims["rccl"].f[:, 1:-1], sims["window"].f[:, 1:-1]))
-            check = "bit-identical to rccl" if same else "MISMATCH: window transport rejected"
-            if not same:
-                del sims["window"]
-        chosen = min(sims, key=lambda k: probe[k])
-        sim = sims.pop(chosen)
-        sims.clear()
-        cand = None
+            # keep only the final populations; candidates must not share the device while timed
+            finals[name] = cand.local_f().clone()
+            cand = None
+            torch.cuda.empty_cache()
+        if not finals:
+            raise SystemExit(f"no usable slab configuration: {probe}")
+        reference = finals.get("single-step/rccl")
+        checks, eligible = {}, []
+        for name, state in finals.items():
+            if reference is not None and state is not reference:
+                same = all_ranks(torch.equal(state, reference))
+                checks[name] = "bit-identical to single-step/rccl" if same else "MISMATCH: rejected"
+                if not same:
+                    continue
+            eligible.append(name)
+        chosen = min(eligible, key=lambda k: probe[k])
+        finals.clear()
+        reference = state = None
         torch.cuda.empty_cache()
+        driver, transport = chosen.split("/")
+        sim = build(driver, transport)              # fresh instance of the chosen configuration
+        sim(args.warmup)
         nodes_per_rank = global_res[0] * global_res[1] * slab.nz_local
         kernel = sim.engine.kernel_name()
         step = sim
-        how = ("RCCL send/recv ghost planes" if chosen == "rccl"
+        how = ("RCCL send/recv ghost planes" if transport == "rccl"
                else "one-sided ghost-plane stores into peer windows (xGMI peer access)")
+        how += ("; two lattice updates per launch, one exchange per two updates" if driver == "two-step"
+                else "; one exchange per update")
         parallelism = f"z-slab x{world}, {how}" + ("" if not args.no_overlap else " (no overlap)")
-        transport_info = {"chosen": chosen, "warmup_ms_per_step": probe, "check": check}
+        transport_info = {"chosen": chosen, "warmup_ms_per_step": probe, "checks": checks}
 
     barrier()
     t0 = time.perf_counter()

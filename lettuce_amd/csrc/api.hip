@@ -680,7 +680,10 @@ const char *lt_plan_kernel_name(lt_plan *p) {
   lt::StepArgs a;
   memset(&a, 0, sizeof a);
   a.layout = p->desc.layout; a.coll = p->desc.collision;
-  a.mode = two_step_wanted(p) ? lt::kFusedTwice : lt::kFused;   // what lt_run's fused section launches
+  // what the fused section launches: lt_run's pairs, or a two-step slab driver on a plan with two
+  // ghost planes
+  a.mode = (two_step_wanted(p) || p->desc.ghost_planes == 2) ? lt::kFusedTwice : lt::kFused;
+  if (a.mode == lt::kFusedTwice && !p->unit.name(a)) a.mode = lt::kFused;
   a.masked = p->masked;
   a.wide = (p->want_wide && p->wide_ok && !a.masked && a.coll == LT_COLLISION_BGK) ? 1 : 0;
   a.shift = a.wide ? p->shift : 0;
