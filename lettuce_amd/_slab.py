@@ -88,6 +88,20 @@ class ZSlab:
                 + self.z_begin) % nz
 
 
+_COMM_STREAMS = {}
+
+
+def _comm_stream(device, priority):
+    """One communication stream per device and priority for the whole process.  torch hands out its
+    pooled streams round-robin and HIP maps them onto a few hardware queues; a fresh stream per
+    simulation made some instances 30-45 % slower than others in the same process (the boundary /
+    exchange work no longer overlapped the interior launch), see tools/slab_history_probe.py."""
+    key = (str(device), int(priority))
+    if key not in _COMM_STREAMS:
+        _COMM_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
+    return _COMM_STREAMS[key]
+
+
 def _crossing_sets(stencil):
     e = np.array(stencil.e)
     up = [int(q) for q in np.nonzero(e[:, 2] == 1)[0]]     # move to +z: fill the lower ghost
@@ -209,8 +223,7 @@ class SlabSimulation:
         shape = [self._message_blocks(flow.stencil), ny, nx]
         new = lambda: torch.empty(shape, dtype=self.f.dtype, device=self.f.device)   # noqa: E731
         self._send_up, self._send_down, self._recv_up, self._recv_down = new(), new(), new(), new()
-        self._comm = (torch.cuda.Stream(device=self.context.device, priority=comm_priority)
-                      if self.overlap else None)
+        self._comm = _comm_stream(self.context.device, comm_priority) if self.overlap else None
         # rehearsal switch: send to / receive from oneself through the process group even with a
         # single rank, to exercise the point-to-point path on a one-GPU box
         self._force_p2p = (os.environ.get("LT_SLAB_FORCE_P2P") == "1" and dist.is_available()
