@@ -782,12 +782,16 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename T, class S, int LAYOUT, int COLL, int T0_, int T1>
-__global__ void __launch_bounds__((TwoStep<T, S, T0_, T1>::THREADS))
+template <typename T, class S, int LAYOUT, int COLL, int T0_, int T1, int NPT = 1>
+__global__ void __launch_bounds__(((TwoStep<T, S, T0_, T1>::NI / NPT + 63) / 64 * 64))
 lbm2_kernel(const KParams<T> p, const int seg_len) {
+  // NPT nodes per thread (1 or 2): thread t owns intermediate nodes t + k NA and output nodes
+  // t + k NB, k < NPT
   using B = TwoStep<T, S, T0_, T1>;
   using M = MemMap<S, LAYOUT>;
   constexpr int T0 = B::T0, H0 = B::H0, NI = B::NI, NO = B::NO;
+  constexpr int NA = NI / NPT, NB = NO / NPT;
+  static_assert(NI % NPT == 0 && NO % NPT == 0, "nodes per thread must divide the tile");
   constexpr int NU = B::template count<LAYOUT, 1>(), NC = B::template count<LAYOUT, 0>(),
                 ND = B::template count<LAYOUT, -1>();
   static_assert(COLL == 0 || COLL == 1, "two-step kernel: streaming only or BGK");
@@ -806,32 +810,38 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   const int t1 = (b % tiles1) * T1; b /= tiles1;
   const int s = p.p_begin + b * seg_len;           // first output plane of this workgroup
 
-  // phase A: node (i0, i1) of the halo'd tile, global coordinates (g0, g1)
-  const bool in_a = tid < NI;
-  const int i1 = tid / H0, i0 = tid - i1 * H0;
-  int g0 = t0 + i0 - 1; g0 = g0 < 0 ? g0 + p.n0 : (g0 >= p.n0 ? g0 - p.n0 : g0);
-  int g1 = t1 + i1 - 1; g1 = g1 < 0 ? g1 + p.n1 : (g1 >= p.n1 ? g1 - p.n1 : g1);
-  // phase B: output node (j0, j1) of the tile
-  const bool in_b = tid < NO;
-  const int j1 = tid / T0, j0 = tid - j1 * T0;
-
+  const bool in_a = tid < NA, in_b = tid < NB;
   // Addresses: the plane part is uniform (scalar registers, recomputed per plane), the in-plane
   // part is a per-thread constant -- nine byte offsets for the nine (e0, e1) pairs of the lattice.
-  const int g0m = g0 == 0 ? p.n0 - 1 : g0 - 1, g0p = g0 == p.n0 - 1 ? 0 : g0 + 1;
-  const int g1m = g1 == 0 ? p.n1 - 1 : g1 - 1, g1p = g1 == p.n1 - 1 ? 0 : g1 + 1;
-  unsigned voff[3][3];                               // [e1 + 1][e0 + 1], bytes within a plane
+  unsigned voff[NPT][3][3];                          // [k][e1 + 1][e0 + 1], bytes within a plane
+  unsigned out_off[NPT];
+  int b_at[NPT];                                     // LDS index of the output node incl. halo offset
+  static_for<NPT>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    // phase A: node (i0, i1) of the halo'd tile, global coordinates (g0, g1)
+    const int ia = tid + k * NA;
+    const int i1 = ia / H0, i0 = ia - i1 * H0;
+    int g0 = t0 + i0 - 1; g0 = g0 < 0 ? g0 + p.n0 : (g0 >= p.n0 ? g0 - p.n0 : g0);
+    int g1 = t1 + i1 - 1; g1 = g1 < 0 ? g1 + p.n1 : (g1 >= p.n1 ? g1 - p.n1 : g1);
+    const int g0m = g0 == 0 ? p.n0 - 1 : g0 - 1, g0p = g0 == p.n0 - 1 ? 0 : g0 + 1;
+    const int g1m = g1 == 0 ? p.n1 - 1 : g1 - 1, g1p = g1 == p.n1 - 1 ? 0 : g1 + 1;
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const int y = a == 0 ? g1p : (a == 1 ? g1 : g1m);     // source = node - e
-      const int x = c == 0 ? g0p : (c == 1 ? g0 : g0m);
-      voff[a][c] = ((unsigned)y * (unsigned)p.n0 + (unsigned)x) * (unsigned)sizeof(T);
-    }
+      for (int c = 0; c < 3; ++c) {
+        const int y = a == 0 ? g1p : (a == 1 ? g1 : g1m);     // source = node - e
+        const int x = c == 0 ? g0p : (c == 1 ? g0 : g0m);
+        voff[k][a][c] = ((unsigned)y * (unsigned)p.n0 + (unsigned)x) * (unsigned)sizeof(T);
+      }
+    // phase B: output node (j0, j1) of the tile
+    const int ib = tid + k * NB;
+    const int j1 = ib / T0, j0 = ib - j1 * T0;
+    out_off[k] = ((unsigned)(t1 + j1) * (unsigned)p.n0 + (unsigned)(t0 + j0)) * (unsigned)sizeof(T);
+    b_at[k] = (j1 + 1) * H0 + (j0 + 1);
+  });
   const unsigned plane_nodes = (unsigned)p.n1 * (unsigned)p.n0;
-  const unsigned out_off = ((unsigned)(t1 + j1) * (unsigned)p.n0 + (unsigned)(t0 + j0)) * (unsigned)sizeof(T);
 
-  T pre[S::Q][1];
+  T pre[S::Q][NPT];
   auto load_a = [&](int plane) {
     // periodic along a2, or a slab whose ghost planes (two per side) hold the neighbours' data
     int g2 = plane, g2m = plane - 1, g2p = plane + 1;
@@ -847,47 +857,61 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
         const int z = e2 == 0 ? g2 : (e2 > 0 ? g2m : g2p);
         // 32-bit scalar multiply (a plane's first node index fits: N < 2^31), 64-bit scalar add
         const T *base = p.in + ((long long)q * p.N + (long long)((unsigned)z * plane_nodes));
-        pre[q][0] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + voff[e1 + 1][e0 + 1]);
+        static_for<NPT>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          pre[q][k] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + voff[k][e1 + 1][e0 + 1]);
+        });
       });
     }
   };
   // r = index of the plane relative to s - 1; r3 = r % 3
   auto compute_a = [&](int r, int r3) {
     if (in_a) {
-      if constexpr (COLL == 1) collide_bgk<T, S, LAYOUT, 1, 0>(pre, p.tau_inv);
+      if constexpr (COLL == 1)
+        static_for<NPT>([&](auto kc) { collide_bgk<T, S, LAYOUT, NPT, decltype(kc)::value>(pre, p.tau_inv); });
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr int e2 = M::e(q, 2), rank = crossing_rank<S, LAYOUT, q>();
-        if constexpr (e2 > 0) lds_u[r & 3][rank][tid] = pre[q][0];
-        else if constexpr (e2 == 0) lds_c[r3][rank][tid] = pre[q][0];
-        else lds_d[r & 1][rank][tid] = pre[q][0];
+        static_for<NPT>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          if constexpr (e2 > 0) lds_u[r & 3][rank][tid + k * NA] = pre[q][k];
+          else if constexpr (e2 == 0) lds_c[r3][rank][tid + k * NA] = pre[q][k];
+          else lds_d[r & 1][rank][tid + k * NA] = pre[q][k];
+        });
       });
     }
   };
-  T f[S::Q][1];
+  T f[S::Q][NPT];
   auto read_b = [&](int r, int r3) {                 // output plane with relative index r
     if (in_b) {
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1), e2 = M::e(q, 2), rank = crossing_rank<S, LAYOUT, q>();
-        const int at = (j1 + 1 - e1) * H0 + (j0 + 1 - e0);
-        if constexpr (e2 > 0) f[q][0] = lds_u[(r - 1) & 3][rank][at];
-        else if constexpr (e2 == 0) f[q][0] = lds_c[r3][rank][at];
-        else f[q][0] = lds_d[(r + 1) & 1][rank][at];
+        static_for<NPT>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          const int at = b_at[k] - e1 * H0 - e0;
+          if constexpr (e2 > 0) f[q][k] = lds_u[(r - 1) & 3][rank][at];
+          else if constexpr (e2 == 0) f[q][k] = lds_c[r3][rank][at];
+          else f[q][k] = lds_d[(r + 1) & 1][rank][at];
+        });
       });
     }
   };
   auto collide_b = [&]() {
     if (in_b) {
-      if constexpr (COLL == 1) collide_bgk<T, S, LAYOUT, 1, 0>(f, p.tau_inv);
+      if constexpr (COLL == 1)
+        static_for<NPT>([&](auto kc) { collide_bgk<T, S, LAYOUT, NPT, decltype(kc)::value>(f, p.tau_inv); });
     }
   };
-  auto store_b = [&](int k) {
+  auto store_b = [&](int k2) {
     if (in_b) {
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        T *base = p.out + ((long long)q * p.N + (long long)((unsigned)k * plane_nodes));
-        __builtin_nontemporal_store(f[q][0], reinterpret_cast<T *>(reinterpret_cast<char *>(base) + out_off));
+        T *base = p.out + ((long long)q * p.N + (long long)((unsigned)k2 * plane_nodes));
+        static_for<NPT>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          __builtin_nontemporal_store(f[q][k], reinterpret_cast<T *>(reinterpret_cast<char *>(base) + out_off[k]));
+        });
       });
     }
   };
