@@ -180,6 +180,13 @@ int lt_slab_unpack(lt_plan *plan, void *f_dev, int64_t plane, int32_t direction,
  * lt_slab_crossing(plan, 0, ...) reports the in-plane populations. */
 int lt_stream_collide_twice_planes(lt_plan *plan, const void *f_dev, void *out_dev, double tau,
                                    int64_t begin, int64_t end, void *stream);
+/* As lt_stream_collide_twice_planes, and in the same launch the halo message for the lower neighbour
+ * (pack_lower_dev != NULL; begin must be the first interior plane) and / or for the upper neighbour
+ * (pack_upper_dev != NULL; end must be one past the last interior plane) is written in the layout of
+ * lt_slab_pack_two_step -- the buffers may be peer-mapped memory of the neighbour. */
+int lt_stream_collide_twice_planes_packed(lt_plan *plan, const void *f_dev, void *out_dev, double tau,
+                                          int64_t begin, int64_t end, void *pack_lower_dev,
+                                          void *pack_upper_dev, void *stream);
 int lt_slab_pack_two_step(lt_plan *plan, const void *f_dev, int32_t side, void *buf_dev, void *stream);
 int lt_slab_unpack_two_step(lt_plan *plan, void *f_dev, int32_t side, const void *buf_dev, void *stream);
 

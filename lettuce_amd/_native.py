@@ -92,6 +92,7 @@ SYMBOLS = {
     "lt_stream_collide_twice": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _vp]),
     "lt_plan_set_two_step": (ctypes.c_int, [_vp, _i32, _i32]),
     "lt_stream_collide_twice_planes": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _i64, _vp]),
+    "lt_stream_collide_twice_planes_packed": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _i64, _vp, _vp, _vp]),
     "lt_slab_pack_two_step": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "lt_slab_unpack_two_step": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "lt_plan_set_fused_events": (ctypes.c_int, [_vp, _vp, _vp]),
@@ -465,6 +466,12 @@ class Plan:
     def stream_collide_twice_planes(self, f, out, tau, begin, end):
         self._check(self.lib.lt_stream_collide_twice_planes(self._handle, _ptr(f), _ptr(out), float(tau),
                                                             int(begin), int(end), _stream_handle()))
+
+    @_on_device
+    def stream_collide_twice_planes_packed(self, f, out, tau, begin, end, pack_lower=None, pack_upper=None):
+        self._check(self.lib.lt_stream_collide_twice_planes_packed(
+            self._handle, _ptr(f), _ptr(out), float(tau), int(begin), int(end), _ptr(pack_lower),
+            _ptr(pack_upper), _stream_handle()))
 
     @_on_device
     def pack_two_step(self, f, side, buf):

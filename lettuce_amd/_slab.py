@@ -471,9 +471,10 @@ class TwoStepSlabSimulation(SlabSimulation):
         planes, and vice versa."""
         eng, s = self.engine, self.slab
         if self._window is not None:
-            to_prev, to_next = self._window.targets()
-            eng.pack_two_step(buf, -1, to_prev)
-            eng.pack_two_step(buf, +1, to_next)
+            if not packed:
+                to_prev, to_next = self._window.targets()
+                eng.pack_two_step(buf, -1, to_prev)
+                eng.pack_two_step(buf, +1, to_next)
             self._window.signal()
 
             def finish_window():
@@ -481,8 +482,9 @@ class TwoStepSlabSimulation(SlabSimulation):
                 eng.unpack_two_step(buf, +1, from_above)
                 eng.unpack_two_step(buf, -1, from_below)
             return finish_window
-        eng.pack_two_step(buf, -1, self._send_down)
-        eng.pack_two_step(buf, +1, self._send_up)
+        if not packed:
+            eng.pack_two_step(buf, -1, self._send_down)
+            eng.pack_two_step(buf, +1, self._send_up)
         if s.world_size == 1 and not self._force_p2p:
             from_above, from_below, reqs = self._send_down, self._send_up, []
         else:
@@ -505,22 +507,34 @@ class TwoStepSlabSimulation(SlabSimulation):
         return finish
 
     # ---- stepping --------------------------------------------------------------------------------
+    def _edges(self, cur, nxt, tau) -> bool:
+        """the output planes next to the two cuts; returns True when the launches also wrote the
+        halo messages (into the send buffers or straight into the neighbours' windows)"""
+        eng, lo, hi, edge = self.engine, self.lo, self.hi, self.edge_planes
+        if hasattr(eng, "stream_collide_twice_planes_packed"):
+            down, up = ((self._send_down, self._send_up) if self._window is None
+                        else self._window.targets())
+            eng.stream_collide_twice_planes_packed(cur, nxt, tau, lo, lo + edge, pack_lower=down)
+            eng.stream_collide_twice_planes_packed(cur, nxt, tau, hi - edge, hi, pack_upper=up)
+            return True
+        eng.stream_collide_twice_planes(cur, nxt, tau, lo, lo + edge)
+        eng.stream_collide_twice_planes(cur, nxt, tau, hi - edge, hi)
+        return False
+
     def _double_step(self, cur, nxt, tau):
         eng, lo, hi = self.engine, self.lo, self.hi
         edge = self.edge_planes
         if self._one_stream and hi - lo >= 2 * edge + 4:
-            eng.stream_collide_twice_planes(cur, nxt, tau, lo, lo + edge)
-            eng.stream_collide_twice_planes(cur, nxt, tau, hi - edge, hi)
-            finish = self._exchange(nxt)          # pack into the neighbours' windows + signal
+            packed = self._edges(cur, nxt, tau)
+            finish = self._exchange(nxt, packed)  # (pack into the neighbours' windows) + signal
             eng.stream_collide_twice_planes(cur, nxt, tau, lo + edge, hi - edge)
             finish()                              # wait for their signals + unpack
         elif self.overlap and hi - lo >= 2 * edge + 4:
             compute = torch.cuda.current_stream()
             self._comm.wait_stream(compute)
             with torch.cuda.stream(self._comm):
-                eng.stream_collide_twice_planes(cur, nxt, tau, lo, lo + edge)
-                eng.stream_collide_twice_planes(cur, nxt, tau, hi - edge, hi)
-                self._exchange(nxt)()
+                packed = self._edges(cur, nxt, tau)
+                self._exchange(nxt, packed)()
             eng.stream_collide_twice_planes(cur, nxt, tau, lo + edge, hi - edge)
             compute.wait_stream(self._comm)
         else:

@@ -752,6 +752,19 @@ int lt_stream_collide_twice_planes(lt_plan *p, const void *f, void *out, double 
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   return step(p, lt::kFusedTwice, f, out, tau, begin, end, stream);
 }
+int lt_stream_collide_twice_planes_packed(lt_plan *p, const void *f, void *out, double tau, int64_t begin,
+                                          int64_t end, void *pack_lower, void *pack_upper, void *stream) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (p->desc.ghost_planes != 2) return fail(LT_ERR_INVALID, "fused two-step packing needs ghost_planes = 2");
+  if (!pack_lower && !pack_upper) return fail(LT_ERR_INVALID, "null pack buffers");
+  if (end - begin < 2) return fail(LT_ERR_INVALID, "the halo message reads two planes: range [%lld, %lld)",
+                                   (long long)begin, (long long)end);
+  if (pack_lower && begin != 2)
+    return fail(LT_ERR_INVALID, "lower message: the range must start at the first interior plane");
+  if (pack_upper && end != p->n2 - 2)
+    return fail(LT_ERR_INVALID, "upper message: the range must end at the last interior plane");
+  return step(p, lt::kFusedTwice, f, out, tau, begin, end, stream, 1, pack_lower, pack_upper);
+}
 int lt_slab_pack_two_step(lt_plan *p, const void *f, int32_t side, void *buf, void *s) {
   return halo2(p, true, const_cast<void *>(f), side, buf, s);
 }

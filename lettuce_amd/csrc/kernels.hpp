@@ -782,7 +782,7 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename T, class S, int LAYOUT, int COLL, int T0_, int T1, int NPT = 1>
+template <typename T, class S, int LAYOUT, int COLL, int T0_, int T1, int NPT = 1, bool PACK = false>
 __global__ void __launch_bounds__(((TwoStep<T, S, T0_, T1>::NI / NPT + 63) / 64 * 64))
 lbm2_kernel(const KParams<T> p, const int seg_len) {
   // NPT nodes per thread (1 or 2): thread t owns intermediate nodes t + k NA and output nodes
@@ -912,6 +912,34 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
           constexpr int k = decltype(kc)::value;
           __builtin_nontemporal_store(f[q][k], reinterpret_cast<T *>(reinterpret_cast<char *>(base) + out_off[k]));
         });
+        // Slab edge launches (PACK) also write the two-step halo message (layout of halo2_kernel: in-plane
+        // populations of the plane next to the cut | its crossing populations | the crossing
+        // populations of the plane behind it), possibly straight into the neighbour's memory.
+        constexpr int e2 = M::e(q, 2), rank = crossing_rank<S, LAYOUT, q>();
+        if constexpr (PACK) {
+        if (p.pack_lo != nullptr && e2 <= 0) {
+          const int d = k2 - p.pack_lo_plane;                    // 0: near plane, 1: far plane
+          if (d == 0 || (d == 1 && e2 < 0)) {
+            const int slot = e2 == 0 ? rank : (d == 0 ? NC + rank : NC + ND + rank);
+            T *msg = p.pack_lo + (size_t)slot * plane_nodes;
+            static_for<NPT>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              *reinterpret_cast<T *>(reinterpret_cast<char *>(msg) + out_off[k]) = f[q][k];
+            });
+          }
+        }
+        if (p.pack_hi != nullptr && e2 >= 0) {
+          const int d = p.pack_hi_plane - k2;
+          if (d == 0 || (d == 1 && e2 > 0)) {
+            const int slot = e2 == 0 ? rank : (d == 0 ? NC + rank : NC + NU + rank);
+            T *msg = p.pack_hi + (size_t)slot * plane_nodes;
+            static_for<NPT>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              *reinterpret_cast<T *>(reinterpret_cast<char *>(msg) + out_off[k]) = f[q][k];
+            });
+          }
+        }
+        }
       });
     }
   };

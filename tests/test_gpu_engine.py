@@ -540,3 +540,22 @@ def test_two_step_on_a_slab_with_two_ghost_planes_equals_two_single_steps():
     assert torch.equal(g[down, n2 - 1], f[down, 3])
     up = np.nonzero(e[:, 2] == 1)[0]
     assert torch.equal(g[up, n2 - 2], f[up, n2 - 2])      # untouched
+
+
+def test_two_step_edge_launch_writes_the_same_halo_message_as_the_pack_kernel():
+    from lettuce_amd._native import Plan, LAYOUT_SLAB
+    plan = Plan("D3Q19", torch.float32, "bgk", [64, 16, 12], [], layout=LAYOUT_SLAB, ghost_planes=2)
+    torch.manual_seed(13)
+    f = (0.05 + 0.01 * torch.rand(plan.f_shape, device="cuda")).contiguous()
+    n2 = f.shape[1]
+    a, b = torch.zeros_like(f), torch.zeros_like(f)
+    plan.stream_collide_twice_planes(f, a, 0.7, 2, n2 - 2)
+    want_down, want_up = torch.empty([19, 16, 64], device="cuda"), torch.empty([19, 16, 64], device="cuda")
+    plan.pack_two_step(a, -1, want_down)
+    plan.pack_two_step(a, +1, want_up)
+    got_down, got_up = torch.zeros_like(want_down), torch.zeros_like(want_up)
+    plan.stream_collide_twice_planes_packed(f, b, 0.7, 2, 5, pack_lower=got_down)
+    plan.stream_collide_twice_planes_packed(f, b, 0.7, n2 - 4, n2 - 2, pack_upper=got_up)
+    assert torch.equal(b[:, 2:5], a[:, 2:5]) and torch.equal(b[:, n2 - 4:n2 - 2], a[:, n2 - 4:n2 - 2])
+    assert torch.equal(got_down, want_down)
+    assert torch.equal(got_up, want_up)
