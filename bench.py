@@ -105,13 +105,19 @@ def traffic_from_profile(kernel_name):
     try:
         with open(path) as fh:
             table = json.load(fh)
-        # the engine's name and rocprofv3's differ only in case and in what follows the argument
-        # list ("void lt::...<...>(lt::KParams<float>)"): compare up to the closing bracket
-        want = kernel_name.lower().replace(" ", "").rstrip(">")
+        # the engine's name and rocprofv3's differ in case, in the "void lt::" prefix and in what
+        # follows the argument list; template parameters appended later (with defaults that keep the
+        # old behaviour) make one name a prefix of the other
+        def core(name):
+            name = name.lower().replace(" ", "")
+            name = name[name.index("lbm"):] if "lbm" in name else name
+            return name.split(">(")[0].rstrip(">")
+        want = core(kernel_name)
         for row in table.get("kernels", []):
-            have = row.get("kernel", "").lower().replace(" ", "")
-            if (row.get("workload") == "tgv3d_d3q19_bgk_f32_256" and want in have
-                    and row.get("hbm_bytes_per_launch")):
+            have = core(row.get("kernel", ""))
+            if (row.get("workload") == "tgv3d_d3q19_bgk_f32_256" and row.get("hbm_bytes_per_launch")
+                    and have.split("<")[0] == want.split("<")[0]
+                    and (want.startswith(have) or have.startswith(want))):
                 return row["hbm_bytes_per_launch"]
     except (OSError, ValueError):
         pass
