@@ -256,16 +256,27 @@ int lt_plan_set_tuning(lt_plan *plan, int32_t cache_policy, int32_t wide);
  * grids without masks or ghost planes whose contiguous extent is a multiple of 64 and whose middle
  * extent is a multiple of 8; LT_ERR_UNSUPPORTED otherwise. */
 int lt_stream_collide_twice(lt_plan *plan, const void *f_dev, void *out_dev, double tau, void *stream);
+/* Small 2-D grids (launch-bound): n_steps <= 8 stream-collide steps in one launch.  Every workgroup
+ * keeps the neighbourhood of its 8 x 8 tile in LDS and recomputes the halo, so the launch does
+ * redundant arithmetic but replaces n_steps launches; bit-identical to n_steps lt_stream_collide
+ * calls.  2-D lattices, no masks, extents multiples of 8; LT_ERR_UNSUPPORTED otherwise.
+ * lt_plan_set_many_step: lt_run / lt_continue use it for their fused steps: -1 = automatic (grids up
+ * to 256 x 256 nodes), 0 = never, 1 = whenever supported. */
+int lt_stream_collide_many(lt_plan *plan, const void *f_dev, void *out_dev, double tau, int32_t n_steps,
+                           void *stream);
+int lt_plan_set_many_step(lt_plan *plan, int32_t mode);
 /* lt_run / lt_continue pair their fused steps with lt_stream_collide_twice where it exists:
  * mode -1 = automatic, 0 = never, 1 = whenever supported.  planes_per_workgroup: segment length of
  * the sweep along the slowest axis (0 = automatic). */
 int lt_plan_set_two_step(lt_plan *plan, int32_t mode, int32_t planes_per_workgroup);
 /* Measurement hooks.  With two hipEvent_t set, lt_run / lt_continue record them on the launch stream
  * around their fused launches (around the two-step launches when there are any, else around the
- * single-step ones); null, null removes them.  lt_plan_last_run_info reports how many fused
- * launches of each kind the last lt_run / lt_continue issued. */
+ * single-step ones, or around the many-step launches); null, null removes them.
+ * lt_plan_last_run_info reports how many fused launches of each kind the last lt_run / lt_continue
+ * issued. */
 int lt_plan_set_fused_events(lt_plan *plan, void *start_event, void *stop_event);
-int lt_plan_last_run_info(lt_plan *plan, int64_t *single_step_launches, int64_t *two_step_launches);
+int lt_plan_last_run_info(lt_plan *plan, int64_t *single_step_launches, int64_t *two_step_launches,
+                          int64_t *many_step_launches);
 /* Workgroups resident per CU for the chip-filling launches (an unused dynamic-LDS allocation caps
  * them): -1 = automatic (3, or 4 for fp32 KBC, once the populations stream from HBM and the launch
  * fills the chip several times over; no cap otherwise), 0 = no cap, 2..8 = that many. */

@@ -96,7 +96,10 @@ SYMBOLS = {
     "lt_slab_pack_two_step": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "lt_slab_unpack_two_step": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "lt_plan_set_fused_events": (ctypes.c_int, [_vp, _vp, _vp]),
-    "lt_plan_last_run_info": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "lt_plan_last_run_info": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                             ctypes.POINTER(ctypes.c_int64)]),
+    "lt_stream_collide_many": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i32, _vp]),
+    "lt_plan_set_many_step": (ctypes.c_int, [_vp, _i32]),
     "lt_probe_copy": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
 }
 
@@ -446,9 +449,23 @@ class Plan:
                                                       ctypes.c_void_p(stop.cuda_event)))
 
     def last_run_info(self):
-        single, twice = ctypes.c_int64(), ctypes.c_int64()
-        self._check(self.lib.lt_plan_last_run_info(self._handle, ctypes.byref(single), ctypes.byref(twice)))
-        return {"single_step_launches": single.value, "two_step_launches": twice.value}
+        single, twice, many = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self._check(self.lib.lt_plan_last_run_info(self._handle, ctypes.byref(single), ctypes.byref(twice),
+                                                   ctypes.byref(many)))
+        return {"single_step_launches": single.value, "two_step_launches": twice.value,
+                "many_step_launches": many.value}
+
+    def set_many_step(self, mode: int = -1):
+        """lt_run on small 2-D grids: several steps per launch (-1 automatic, 0 never, 1 when supported)"""
+        self._check(self.lib.lt_plan_set_many_step(self._handle, int(mode)))
+
+    @_on_device
+    def stream_collide_many(self, f, out, tau, n_steps):
+        """out = (collide o stream)^n_steps f in one launch (small 2-D grids, n_steps <= 8)"""
+        self._tensor_ok(f, self.f_shape); self._tensor_ok(out, self.f_shape)
+        self._check(self.lib.lt_stream_collide_many(self._handle, _ptr(f), _ptr(out), float(tau), int(n_steps),
+                                                    _stream_handle()))
+        return out
 
     def set_two_step(self, mode: int = -1, planes_per_workgroup: int = 0):
         """lt_run pairs fused steps into two-step launches: -1 automatic, 0 never, 1 when supported"""

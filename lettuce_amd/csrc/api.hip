@@ -80,8 +80,10 @@ struct lt_plan {
   int n_cu = 0;              // compute units of the plan's device
   int two_step = -1;         // lt_run: pair the fused steps (lbm2_kernel): -1 = automatic, 0 / 1
   int seg_len = 0;           // planes per workgroup of the two-step kernel, 0 = automatic
+  int many = -1;             // lt_run: several steps per launch on small 2-D grids: -1 = automatic, 0 / 1
+  int many_now = 1;          // steps of the kFusedMany launch being issued
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // lt_plan_set_fused_events
-  long long last_single = 0, last_twice = 0;          // fused launches of the last lt_run
+  long long last_single = 0, last_twice = 0, last_many = 0;   // fused launches of the last lt_run
   int want_wide = 0;         // 16-byte accesses for the hot kernel (A/B experiments)
   // engine-owned device scratch
   unsigned char *node = nullptr;
@@ -297,6 +299,8 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   if (p->desc.ghost_planes && (pb < 1 || pe > p->n2 - 1) && mode != lt::kCollideOnly && pe > pb)
     return fail(LT_ERR_INVALID, "streaming from ghost planes: range [%lld, %lld) must stay in [1, %d)",
                 pb, pe, p->n2 - 1);
+  if (mode == lt::kFusedMany && (p->masked || p->desc.ghost_planes))
+    return fail(LT_ERR_UNSUPPORTED, "several steps per launch: no masks / boundaries / slabs");
   if (mode == lt::kFusedTwice) {
     if (p->desc.ghost_planes == 1)
       return fail(LT_ERR_INVALID, "two steps per launch read two planes beyond the range: the plan needs "
@@ -329,6 +333,7 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.lds_bytes = resolve_lds(p, ((long long)a.planes * a.n1 * a.n0 + 255) / 256);
   a.seg_len = mode == lt::kFusedTwice ? resolve_seg_len(p, a.planes) : 0;
   if (mode == lt::kFusedTwice) a.shift = p->shift;      // tile-shape A/B variant
+  if (mode == lt::kFusedMany) a.seg_len = p->many_now;
   a.stream = static_cast<hipStream_t>(stream);
   a.pack_lo = pack_lo; a.pack_hi = pack_hi;
   a.pack_lo_plane = (int)pb; a.pack_hi_plane = (int)(pb + stride * (a.planes - 1));
@@ -411,6 +416,22 @@ bool two_step_wanted(lt_plan *p) {
   return bytes > (128ll << 20);
 }
 
+constexpr int kManyMax = 8;        // == kManyMax of unit.inc
+
+// Several steps per launch (lbm_many_kernel): 2-D, no masks, tiles of 8 x 8.  Every workgroup
+// recomputes a halo of K - 1 nodes around its tile, so this only pays while the grid is
+// launch-bound; "automatic" stops at 256 x 256 nodes (measured, tools/small_grid_bench.py).
+bool many_step_wanted(lt_plan *p) {
+  if (p->many == 0 || p->masked || p->desc.ghost_planes || p->unit.d != 2) return false;
+  if (p->n0 % 8 != 0 || p->n1 % 8 != 0) return false;
+  lt::StepArgs a;
+  memset(&a, 0, sizeof a);
+  a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = lt::kFusedMany;
+  if (!p->unit.name(a)) return false;
+  if (p->many == 1) return true;
+  return p->N <= 256ll * 256ll;
+}
+
 int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, void *stream,
         int32_t *result_in_b) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
@@ -435,9 +456,24 @@ int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, 
   }
   // fused section: pairs of steps through the two-step kernel where it applies, the rest one by
   // one.  The optional events bracket the dominant kind of launch only.
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  p->last_many = 0;
+  if (many_step_wanted(p) && fused >= 2) {
+    // launches of up to kManyMax steps each; the events bracket them
+    if (p->ev_start) (void)hipEventRecord(p->ev_start, hs);
+    while (fused > 0) {
+      p->many_now = fused < kManyMax ? (int)fused : kManyMax;
+      rc = step(p, lt::kFusedMany, cur, other, tau, 0, p->n2, stream);
+      if (rc) return rc;
+      void *t = cur; cur = other; other = t;
+      fused -= p->many_now;
+      ++p->last_many;
+    }
+    if (p->ev_stop) (void)hipEventRecord(p->ev_stop, hs);
+    p->last_twice = p->last_single = 0;
+  } else {
   const long long twice = two_step_wanted(p) ? fused / 2 : 0;
   const long long single = fused - 2 * twice;
-  hipStream_t hs = static_cast<hipStream_t>(stream);
   p->last_twice = twice; p->last_single = single;
   if (p->ev_start && twice > 0) (void)hipEventRecord(p->ev_start, hs);
   for (long long i = 0; i < twice; ++i) {
@@ -453,6 +489,7 @@ int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, 
     void *t = cur; cur = other; other = t;
   }
   if (p->ev_stop && twice == 0) (void)hipEventRecord(p->ev_stop, hs);
+  }
   rc = step(p, lt::kStreamOnly, cur, other, tau, 0, p->n2, stream);
   if (rc) return rc;
   *result_in_b = (other == b) ? 1 : 0;
@@ -683,6 +720,7 @@ const char *lt_plan_kernel_name(lt_plan *p) {
   // what the fused section launches: lt_run's pairs, or a two-step slab driver on a plan with two
   // ghost planes
   a.mode = (two_step_wanted(p) || p->desc.ghost_planes == 2) ? lt::kFusedTwice : lt::kFused;
+  if (many_step_wanted(p)) a.mode = lt::kFusedMany;
   if (a.mode == lt::kFusedTwice && !p->unit.name(a)) a.mode = lt::kFused;
   a.masked = p->masked;
   a.wide = (p->want_wide && p->wide_ok && !a.masked && a.coll == LT_COLLISION_BGK) ? 1 : 0;
@@ -781,10 +819,26 @@ int lt_plan_set_fused_events(lt_plan *p, void *start_event, void *stop_event) {
   return LT_OK;
 }
 
-int lt_plan_last_run_info(lt_plan *p, int64_t *single_step_launches, int64_t *two_step_launches) {
+int lt_plan_last_run_info(lt_plan *p, int64_t *single_step_launches, int64_t *two_step_launches,
+                          int64_t *many_step_launches) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (single_step_launches) *single_step_launches = p->last_single;
   if (two_step_launches) *two_step_launches = p->last_twice;
+  if (many_step_launches) *many_step_launches = p->last_many;
+  return LT_OK;
+}
+
+int lt_stream_collide_many(lt_plan *p, const void *f, void *out, double tau, int32_t n_steps, void *stream) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (n_steps < 1 || n_steps > kManyMax) return fail(LT_ERR_INVALID, "n_steps = %d (1..%d per launch)", n_steps, kManyMax);
+  p->many_now = n_steps;
+  return step(p, lt::kFusedMany, f, out, tau, 0, p->n2, stream);
+}
+
+int lt_plan_set_many_step(lt_plan *p, int32_t mode) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (mode < -1 || mode > 1) return fail(LT_ERR_INVALID, "many-step mode %d", mode);
+  p->many = mode;
   return LT_OK;
 }
 

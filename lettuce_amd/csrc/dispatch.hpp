@@ -6,7 +6,7 @@
 
 namespace lt {
 
-enum StepMode { kFused = 0, kCollideOnly = 1, kStreamOnly = 2, kFusedTwice = 3 };
+enum StepMode { kFused = 0, kCollideOnly = 1, kStreamOnly = 2, kFusedTwice = 3, kFusedMany = 4 };
 
 struct StepArgs {
   const void *in;
@@ -22,7 +22,7 @@ struct StepArgs {
   int nb;
   int layout, coll, mode, masked, wide, shift, tune;
   int lds_bytes;         // unused dynamic LDS per workgroup (residency cap), 0 = none
-  int seg_len;           // kFusedTwice: a2 planes per workgroup
+  int seg_len;           // kFusedTwice: a2 planes per workgroup; kFusedMany: steps in this launch
   void *pack_lo, *pack_hi;         // fused halo packing (slab boundary launch) or null
   int pack_lo_plane, pack_hi_plane;
   hipStream_t stream;

@@ -965,6 +965,82 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   }
 }
 
+// ---- up to KMAX steps per launch on small 2-D grids ---------------------------------------------
+// A 128^2 grid is launch-bound (3.5 us per step against < 1 us of work).  Here a workgroup loads the
+// (TO0 + 2(K-1)) x (TO1 + 2(K-1)) neighbourhood of its TO0 x TO1 tile, performs K stream-collide
+// steps on it in LDS (two buffers, one __syncthreads per step; after step s only the nodes at
+// distance >= s-1 from the border of the neighbourhood are still valid, after step K exactly the
+// tile) and stores the tile.  The neighbourhood is recomputed by every workgroup that needs it --
+// free while the GPU waits for launches, which is why lt_run only uses this on small grids.
+// Same pull and same collide as the one-step kernel: K launches of lbm_kernel give the same bits.
+template <int TO0, int TO1, int KMAX>
+struct ManyStep2D {
+  static constexpr int R0 = TO0 + 2 * (KMAX - 1), R1 = TO1 + 2 * (KMAX - 1);
+  static constexpr int NR = R0 * R1;
+  static constexpr int THREADS = (NR + 63) / 64 * 64;
+};
+
+template <typename T, class S, int COLL, int TO0, int TO1, int KMAX>
+__global__ void __launch_bounds__((ManyStep2D<TO0, TO1, KMAX>::THREADS))
+lbm_many_kernel(const KParams<T> p, const int K) {
+  static_assert(S::D == 2, "2-D lattices");
+  using M = MemMap<S, 0>;
+  using G = ManyStep2D<TO0, TO1, KMAX>;
+  __shared__ T lds[2][S::Q][G::NR];
+  const int tid = threadIdx.x;
+  const int halo = K - 1;
+  const int r0 = TO0 + 2 * halo, r1 = TO1 + 2 * halo;        // neighbourhood of this launch
+  const int tiles0 = p.n0 / TO0;
+  const int t0 = (blockIdx.x % tiles0) * TO0, t1 = (blockIdx.x / tiles0) * TO1;
+  const bool in_region = tid < r0 * r1;
+  const int i1 = tid / r0, i0 = tid - i1 * r0;
+  auto wrap = [](int x, int n) { x %= n; return x < 0 ? x + n : x; };
+  const int g0 = wrap(t0 - halo + i0, p.n0), g1 = wrap(t1 - halo + i1, p.n1);
+  auto collide = [&](T (&f)[S::Q][1]) {
+    if constexpr (COLL == 1) collide_bgk<T, S, 0, 1, 0>(f, p.tau_inv);
+    if constexpr (COLL == 2) collide_kbc<T, S, 0, 1, 0>(f, p.beta, p.inv_beta);
+  };
+  T f[S::Q][1];
+  // step 1: pull from global memory, every node of the neighbourhood
+  if (in_region) {
+    static_for<S::Q>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1);
+      const int s0 = e0 == 0 ? g0 : wrap(g0 - e0, p.n0), s1 = e1 == 0 ? g1 : wrap(g1 - e1, p.n1);
+      f[q][0] = p.in[(long long)q * p.N + (long long)s1 * p.n0 + s0];
+    });
+    collide(f);
+  }
+  for (int s = 1; s < K; ++s) {                 // f holds the state after step s
+    const int buf = s & 1;
+    if (in_region) {
+      static_for<S::Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        lds[buf][q][i1 * G::R0 + i0] = f[q][0];
+      });
+    }
+    __syncthreads();
+    // step s + 1 is valid for nodes at distance >= s from the border
+    const bool valid = in_region && i0 >= s && i0 < r0 - s && i1 >= s && i1 < r1 - s;
+    if (valid) {
+      static_for<S::Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1);
+        f[q][0] = lds[buf][q][(i1 - e1) * G::R0 + (i0 - e0)];
+      });
+      collide(f);
+    }
+  }
+  // after K steps the valid nodes are the tile
+  if (in_region && i0 >= halo && i0 < r0 - halo && i1 >= halo && i1 < r1 - halo) {
+    const long long own = (long long)g1 * p.n0 + g0;
+    static_for<S::Q>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      p.out[(long long)q * p.N + own] = f[q][0];
+    });
+  }
+}
+
 // ---- auxiliary kernels --------------------------------------------------------------------
 // rho [N], u [d][N] (logical axis order) from f  -- Flow.rho / Flow.u
 template <typename T, class S, int LAYOUT>

@@ -559,3 +559,40 @@ def test_two_step_edge_launch_writes_the_same_halo_message_as_the_pack_kernel():
     assert torch.equal(b[:, 2:5], a[:, 2:5]) and torch.equal(b[:, n2 - 4:n2 - 2], a[:, n2 - 4:n2 - 2])
     assert torch.equal(got_down, want_down)
     assert torch.equal(got_up, want_up)
+
+
+# --------------------------------------------------------------------------- many steps per launch (2-D)
+@pytest.mark.parametrize("res", [[8, 8], [16, 24], [128, 128], [40, 8]])
+@pytest.mark.parametrize("coll,dt", [("bgk", "f64"), ("bgk", "f32"), ("none", "f32"), ("kbc", "f64")])
+def test_many_steps_per_launch_equal_single_steps(res, coll, dt):
+    """lt_stream_collide_many (K <= 8 steps in LDS, recomputed halo, neighbourhoods that wrap around
+    tiny grids several times) against K lt_stream_collide launches, every K."""
+    plan = plan_for("D2Q9", TORCH_DT[dt], coll, res)
+    torch.manual_seed(17)
+    w = torch.tensor(orc.LATTICES["D2Q9"].w, dtype=TORCH_DT[dt], device="cuda").reshape(9, 1, 1)
+    f = (w * (1 + 0.1 * torch.rand([9] + res, dtype=TORCH_DT[dt], device="cuda"))).contiguous()
+    a, b = f.clone(), torch.empty_like(f)
+    for k in range(1, 9):
+        plan.stream_collide(a, b, 0.7)
+        a, b = b, a
+        got = torch.empty_like(f)
+        plan.stream_collide_many(f, got, 0.7, k)
+        assert torch.equal(got, a), k
+
+
+def test_lt_run_uses_many_step_launches_on_small_2d_grids():
+    """cfg1's shape: lt_run issues ceil((n-1)/8) launches for its fused steps and the populations are
+    those of the step-by-step path (and bit-identical to the reference vectors, tested elsewhere)."""
+    res = [128, 128]
+    w = torch.tensor(orc.LATTICES["D2Q9"].w, dtype=torch.float64, device="cuda").reshape(9, 1, 1)
+    torch.manual_seed(19)
+    f0 = (w * (1 + 0.1 * torch.rand([9] + res, dtype=torch.float64, device="cuda"))).contiguous()
+    outs = []
+    for mode in (0, -1):
+        plan = plan_for("D2Q9", torch.float64, "bgk", res)
+        plan.set_many_step(mode)
+        r, other = plan.run(f0.clone(), torch.empty_like(f0), 0.61, 20)
+        info = plan.last_run_info()
+        assert info["many_step_launches"] == (0 if mode == 0 else 3)       # 19 fused steps = 8 + 8 + 3
+        outs.append((r.clone(), other.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
