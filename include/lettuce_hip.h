@@ -252,8 +252,8 @@ int lt_plan_set_graph_mode(lt_plan *plan, int32_t mode);
 int lt_plan_set_tuning(lt_plan *plan, int32_t cache_policy, int32_t wide);
 /* Two fused steps in one launch: out = (C S)^2 f for the whole periodic grid, the intermediate
  * state staged through LDS (one HBM read and one write of the populations per two lattice updates).
- * Bit-identical to two lt_stream_collide calls.  Exists for D3Q19 fp32 with BGK / no collision on
- * grids without masks or ghost planes whose contiguous extent is a multiple of 64 and whose middle
+ * Bit-identical to two lt_stream_collide calls.  Exists for D3Q19 with BGK / no collision on grids
+ * without masks whose contiguous extent is a multiple of 64 (fp32) / 32 (fp64) and whose middle
  * extent is a multiple of 8; LT_ERR_UNSUPPORTED otherwise. */
 int lt_stream_collide_twice(lt_plan *plan, const void *f_dev, void *out_dev, double tau, void *stream);
 /* Small 2-D grids (launch-bound): n_steps <= 8 stream-collide steps in one launch.  Every workgroup

@@ -236,7 +236,7 @@ int resolve_lds(const lt_plan *p, long long workgroups) {
 // with 32 planes and 0.52 with 256, which leaves half the CUs idle).
 int resolve_seg_len(const lt_plan *p, int planes) {
   if (p->seg_len > 0) return p->seg_len;
-  const long long tiles = (long long)(p->n0 / 64) * (p->n1 / 8);
+  const long long tiles = (long long)(p->n0 / (p->esize == 4 ? 64 : 32)) * (p->n1 / 8);
   const long long cus = p->n_cu > 0 ? p->n_cu : 256;
   int best = 1;
   double best_score = -1.0;
@@ -406,7 +406,7 @@ long long run_graph(lt_plan *p, void *cur, void *other, double tau, long long fu
 // asks for the streaming regime (populations beyond the caches), where halving the HBM passes pays.
 bool two_step_wanted(lt_plan *p) {
   if (p->two_step == 0 || p->masked || p->desc.ghost_planes) return false;
-  if (p->n0 % 64 != 0 || p->n1 % 8 != 0) return false;
+  if (p->n0 % (p->esize == 4 ? 64 : 32) != 0 || p->n1 % 8 != 0) return false;
   lt::StepArgs a;
   memset(&a, 0, sizeof a);
   a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = lt::kFusedTwice;

@@ -458,15 +458,16 @@ def test_cfg1_populations_bit_identical_after_100_steps():
 @pytest.mark.parametrize("res,seg", [([4, 8, 64], 0), ([8, 16, 64], 4), ([6, 24, 128], 3), ([1, 8, 64], 1),
                                      ([12, 40, 192], 0), ([5, 8, 64], 5)])
 @pytest.mark.parametrize("coll", ["none", "bgk"])
-def test_two_step_launch_is_bit_identical_to_two_single_steps(res, seg, coll):
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_two_step_launch_is_bit_identical_to_two_single_steps(res, seg, coll, dt):
     """lt_stream_collide_twice (intermediate state in LDS, halo'd tiles, plane sweep with wrap) against
     two lt_stream_collide launches: every segment length incl. 1, tiles that wrap in both tiled
-    axes, several tiles per axis."""
-    plan = plan_for("D3Q19", torch.float32, coll, res)
+    axes, several tiles per axis; fp32 (64 x 8 tiles) and fp64 (32 x 8 tiles)."""
+    plan = plan_for("D3Q19", TORCH_DT[dt], coll, res)
     plan.set_two_step(1, seg)
     torch.manual_seed(3)
-    w = torch.rand(19, 1, 1, 1, device="cuda") * 0.05 + 0.02
-    f = (w * (1 + 0.1 * torch.rand(plan.f_shape, device="cuda"))).contiguous()
+    w = torch.rand(19, 1, 1, 1, device="cuda", dtype=TORCH_DT[dt]) * 0.05 + 0.02
+    f = (w * (1 + 0.1 * torch.rand(plan.f_shape, device="cuda", dtype=TORCH_DT[dt]))).contiguous()
     a, b, c = torch.empty_like(f), torch.empty_like(f), torch.empty_like(f)
     plan.stream_collide(f, a, 0.6)
     plan.stream_collide(a, b, 0.6)
@@ -500,8 +501,9 @@ def test_lt_run_with_paired_steps_equals_lt_run_without(n):
 
 def test_two_step_unsupported_combinations_fail_loudly():
     from lettuce_amd._native import NativeEngineError
-    for lat, dt, coll, res in (("D3Q27", torch.float32, "bgk", [4, 8, 64]), ("D3Q19", torch.float64, "bgk", [4, 8, 64]),
-                               ("D3Q19", torch.float32, "bgk", [4, 8, 60]), ("D3Q19", torch.float32, "bgk", [4, 6, 64])):
+    for lat, dt, coll, res in (("D3Q27", torch.float32, "bgk", [4, 8, 64]), ("D3Q19", torch.float64, "bgk", [4, 8, 48]),
+                               ("D3Q19", torch.float32, "bgk", [4, 8, 96]), ("D3Q19", torch.float32, "bgk", [4, 6, 64]),
+                               ("D3Q15", torch.float32, "bgk", [4, 8, 64])):
         plan = plan_for(lat, dt, coll, res)
         f = torch.rand(plan.f_shape, device="cuda", dtype=dt)
         with pytest.raises(NativeEngineError):

@@ -51,21 +51,23 @@ def test_ranks_sharing_one_gpu(tmp_path, world, overlap):
     assert float(got["ke"]) == pytest.approx(float(orc.kinetic_energy_pu(ref.f, ref.lat, ref.units)), rel=1e-11)
 
 
-@pytest.mark.parametrize("world,overlap,steps", [(2, True, 7), (2, False, 6), (3, True, 4)],
-                         ids=["2ranks-overlap-7steps", "2ranks-serial-6steps", "3ranks-overlap-4steps"])
-def test_two_step_slab_ranks_sharing_one_gpu(tmp_path, world, overlap, steps):
+@pytest.mark.parametrize("world,overlap,steps,dtype_name", [(2, True, 7, "float32"), (2, False, 6, "float32"),
+                                                            (3, True, 4, "float32"), (2, True, 5, "float64")],
+                         ids=["2ranks-overlap-7steps", "2ranks-serial-6steps", "3ranks-overlap-4steps", "2ranks-fp64"])
+def test_two_step_slab_ranks_sharing_one_gpu(tmp_path, world, overlap, steps, dtype_name):
     """TwoStepSlabSimulation with the real kernels (lt_stream_collide_twice_planes on slabs with two
     ghost planes, lt_slab_pack/unpack_two_step) on 2-3 gloo ranks sharing the GPU, fp32, against the
     single-domain oracle; boundary / interior launches on two streams when overlapping."""
     from oracle import lettuce_oracle as orc
     res = [64, 16, 12 * world]
     port = 29600 + (os.getpid() % 1000) + int(overlap) + 10 * world
-    mp.spawn(_worker, args=(world, port, res, steps, "float32", overlap, str(tmp_path), "TwoStepSlabSimulation"),
+    mp.spawn(_worker, args=(world, port, res, steps, dtype_name, overlap, str(tmp_path), "TwoStepSlabSimulation"),
              nprocs=world, join=True)
     got = np.load(tmp_path / "out.npz")
-    ref = orc.taylor_green(res, 400, 0.1, "D3Q19", torch.float32)
+    ref = orc.taylor_green(res, 400, 0.1, "D3Q19", getattr(torch, dtype_name))
     ref.step(steps)
-    np.testing.assert_allclose(got["f1"], ref.f.numpy(), rtol=0, atol=1e-5 * float(np.abs(ref.f.numpy()).max()))
+    tol = 1e-5 if dtype_name == "float32" else 1e-13
+    np.testing.assert_allclose(got["f1"], ref.f.numpy(), rtol=0, atol=tol * float(np.abs(ref.f.numpy()).max()))
 
 
 def _two_step_identity_worker(rank, port, res, steps, transport, out_dir):
