@@ -475,6 +475,28 @@ def test_two_step_launch_is_bit_identical_to_two_single_steps(res, seg, coll, dt
     assert torch.equal(b, c)
 
 
+@pytest.mark.parametrize("lat,dt", [("D3Q15", "f32"), ("D3Q15", "f64"), ("D3Q27", "f32")])
+def test_two_step_launch_on_the_other_lattices(lat, dt):
+    """the kernel is generic in the lattice; the tile is 64 x 8 or 32 x 8 depending on what fits LDS"""
+    res = [5, 16, 128]
+    plan = plan_for(lat, TORCH_DT[dt], "bgk", res)
+    torch.manual_seed(23)
+    L = orc.LATTICES[lat]
+    w = torch.tensor(L.w, dtype=TORCH_DT[dt], device="cuda").reshape(L.q, 1, 1, 1)
+    f = (w * (1 + 0.1 * torch.rand([L.q] + res, dtype=TORCH_DT[dt], device="cuda"))).contiguous()
+    a, b, c = torch.empty_like(f), torch.empty_like(f), torch.empty_like(f)
+    plan.stream_collide(f, a, 0.8)
+    plan.stream_collide(a, b, 0.8)
+    plan.stream_collide_twice(f, c, 0.8)
+    assert torch.equal(b, c)
+    sim = orc.OracleSimulation(L, f.cpu().clone(), "bgk", 0.8)
+    plan.set_two_step(1)
+    r, _ = plan.run(f.clone(), torch.empty_like(f), 0.8, 5)
+    assert plan.last_run_info()["two_step_launches"] == 2
+    sim.step(5)
+    assert_close(r.cpu().numpy(), sim.f.numpy(), dt)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 7, 8])
 def test_lt_run_with_paired_steps_equals_lt_run_without(n):
     """odd and even numbers of fused steps: pairs through the two-step kernel plus a single one"""
@@ -501,9 +523,9 @@ def test_lt_run_with_paired_steps_equals_lt_run_without(n):
 
 def test_two_step_unsupported_combinations_fail_loudly():
     from lettuce_amd._native import NativeEngineError
-    for lat, dt, coll, res in (("D3Q27", torch.float32, "bgk", [4, 8, 64]), ("D3Q19", torch.float64, "bgk", [4, 8, 48]),
+    for lat, dt, coll, res in (("D3Q27", torch.float64, "bgk", [4, 8, 64]), ("D3Q19", torch.float64, "bgk", [4, 8, 48]),
                                ("D3Q19", torch.float32, "bgk", [4, 8, 96]), ("D3Q19", torch.float32, "bgk", [4, 6, 64]),
-                               ("D3Q15", torch.float32, "bgk", [4, 8, 64])):
+                               ("D3Q27", torch.float32, "kbc", [4, 8, 64])):
         plan = plan_for(lat, dt, coll, res)
         f = torch.rand(plan.f_shape, device="cuda", dtype=dt)
         with pytest.raises(NativeEngineError):
