@@ -310,6 +310,11 @@ def main():
                     "lattice_updates_per_launch": updates_per_launch,
                     "algorithmic_bytes_per_launch": BYTES_PER_NODE * updates_per_launch,
                     "launches_timed": launches}
+        if roofline["traffic"]:
+            # what HBM really carried per second during the launch (PMC bytes / live duration)
+            real = roofline["traffic"] / (fused_ms * 1e-3) / 1e9
+            roofline["hbm_traffic_GBps"] = round(real, 1)
+            roofline["hbm_traffic_frac_of_peak"] = round(real / HBM_PEAK_GBS, 4)
         if paired:
             roofline["note"] = ("two lattice updates per node per launch, the intermediate state staged "
                                 "in LDS: HBM traffic per launch (traffic) is below the algorithmic bytes "
