@@ -815,12 +815,23 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   // part is a per-thread constant -- nine byte offsets for the nine (e0, e1) pairs of the lattice.
   unsigned voff[NPT][3][3];                          // [k][e1 + 1][e0 + 1], bytes within a plane
   unsigned out_off[NPT];
+  int a_at[NPT];                                     // LDS index of the intermediate node
   int b_at[NPT];                                     // LDS index of the output node incl. halo offset
   static_for<NPT>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    // phase A: node (i0, i1) of the halo'd tile, global coordinates (g0, g1)
+    // phase A: node (i0, i1) of the halo'd tile, global coordinates (g0, g1).  The T0 inner columns
+    // of a row go to T0 consecutive threads (a wave reads one aligned 256-byte row segment per
+    // population), the two halo columns of all rows to the last threads.
     const int ia = tid + k * NA;
-    const int i1 = ia / H0, i0 = ia - i1 * H0;
+    int i1, i0;
+    if (NPT == 1) {
+      constexpr int inner = T0 * B::H1;
+      i1 = ia < inner ? ia / T0 : (ia - inner) >> 1;
+      i0 = ia < inner ? 1 + (ia - i1 * T0) : (((ia - inner) & 1) ? H0 - 1 : 0);
+    } else {
+      i1 = ia / H0; i0 = ia - i1 * H0;
+    }
+    a_at[k] = i1 * H0 + i0;
     int g0 = t0 + i0 - 1; g0 = g0 < 0 ? g0 + p.n0 : (g0 >= p.n0 ? g0 - p.n0 : g0);
     int g1 = t1 + i1 - 1; g1 = g1 < 0 ? g1 + p.n1 : (g1 >= p.n1 ? g1 - p.n1 : g1);
     const int g0m = g0 == 0 ? p.n0 - 1 : g0 - 1, g0p = g0 == p.n0 - 1 ? 0 : g0 + 1;
@@ -874,9 +885,9 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
         constexpr int e2 = M::e(q, 2), rank = crossing_rank<S, LAYOUT, q>();
         static_for<NPT>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
-          if constexpr (e2 > 0) lds_u[r & 3][rank][tid + k * NA] = pre[q][k];
-          else if constexpr (e2 == 0) lds_c[r3][rank][tid + k * NA] = pre[q][k];
-          else lds_d[r & 1][rank][tid + k * NA] = pre[q][k];
+          if constexpr (e2 > 0) lds_u[r & 3][rank][a_at[k]] = pre[q][k];
+          else if constexpr (e2 == 0) lds_c[r3][rank][a_at[k]] = pre[q][k];
+          else lds_d[r & 1][rank][a_at[k]] = pre[q][k];
         });
       });
     }
