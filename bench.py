@@ -203,7 +203,7 @@ def main():
         # Candidates: slab driver (two lattice updates per launch and one halo exchange per two
         # updates / one update per launch) x transport (RCCL send/recv / one-sided peer windows).
         # The single-step driver over RCCL is the reference: every candidate does 3 + W warm-up
-        # steps from the same initial state (the W timed, max over ranks), must end with populations
+        # steps from the same initial state (two timed batches of max(W, 60) steps, max over ranks), must end with populations
         # bit-identical to the reference's on every rank, and the fastest eligible one runs the
         # timed K steps.  All warm-up rates go into the JSON line.
         transports = ["rccl", "window"] if args.transport == "auto" else [args.transport]
@@ -213,6 +213,7 @@ def main():
             wanted = [("single-step", "rccl")] + [w for w in wanted if w != ("single-step", "rccl")]
         finals, probe = {}, {}
         window_ok = None
+        probe_steps = max(args.warmup, 60)
         for driver, transport in wanted:
             name = f"{driver}/{transport}"
             if transport == "window":
@@ -241,13 +242,16 @@ def main():
                 probe.setdefault(name, "unavailable on another rank")
                 cand = None
                 continue
-            barrier()
-            t0 = time.perf_counter()
-            cand(max(args.warmup, 1))
-            barrier()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            probe[name] = round(float(t.item()) / max(args.warmup, 1) * 1e3, 5)
+            best = None
+            for _ in range(2):                  # two batches of >= 60 steps, the faster one counts
+                barrier()
+                t0 = time.perf_counter()
+                cand(probe_steps)
+                barrier()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                best = float(t.item()) if best is None else min(best, float(t.item()))
+            probe[name] = round(best / probe_steps * 1e3, 5)
             # keep only the final populations; candidates must not share the device while timed
             finals[name] = cand.local_f().clone()
             cand = None
