@@ -244,8 +244,9 @@ class SlabSimulation:
                                        "process group")
             self._window = _PeerWindow(shape, self.f.dtype, self.f.device, slab, group)
         # window transport: the exchange can ride on the compute stream (see _fused_step); measured
-        # on MI355X the single-step driver is better off with two streams (0.437 vs 0.454 ms/step),
-        # the two-step driver with one (0.356 vs 0.361)
+        # on one MI355X the single-step driver is better off with two streams (0.437 vs 0.454
+        # ms/step), the two-step driver marginally with one (0.356 vs 0.361) -- see
+        # TwoStepSlabSimulation.ONE_STREAM_WINDOWS for why two streams are the default anyway
         self._one_stream = self._window is not None and self.overlap and self.ONE_STREAM_WINDOWS
 
     def _message_blocks(self, stencil) -> int:
@@ -447,7 +448,10 @@ class TwoStepSlabSimulation(SlabSimulation):
     """
 
     GHOST = 2
-    ONE_STREAM_WINDOWS = True
+    # With windows the exchange could ride on the compute stream (stores + signal before the interior
+    # launch, wait + unpack after it); on one GPU that is 1.5 % faster, but across xGMI the pack
+    # launch takes as long as the transfer and would delay the interior launch: two streams.
+    ONE_STREAM_WINDOWS = os.environ.get("LT_SLAB_ONE_STREAM") == "1"
 
     def __init__(self, flow, collision, slab: ZSlab, **kwargs):
         if flow.boundaries:
@@ -511,7 +515,13 @@ class TwoStepSlabSimulation(SlabSimulation):
         """the output planes next to the two cuts; returns True when the launches also wrote the
         halo messages (into the send buffers or straight into the neighbours' windows)"""
         eng, lo, hi, edge = self.engine, self.lo, self.hi, self.edge_planes
-        if hasattr(eng, "stream_collide_twice_planes_packed"):
+        # Fused packing only into local send buffers.  With peer windows the message is 20 MB of
+        # stores over one xGMI link per direction (~0.3-0.4 ms): inside the edge launch they would
+        # hold all CUs (one workgroup per CU, 150 KB of LDS) for that long, so a separate light pack
+        # launch does them beside the interior launch instead (LT_SLAB_FUSED_REMOTE_PACK=1 to A/B;
+        # on one GPU, where the "remote" stores are local, fusing is 2 % faster).
+        fuse = self._window is None or os.environ.get("LT_SLAB_FUSED_REMOTE_PACK") == "1"
+        if fuse and hasattr(eng, "stream_collide_twice_planes_packed"):
             down, up = ((self._send_down, self._send_up) if self._window is None
                         else self._window.targets())
             eng.stream_collide_twice_planes_packed(cur, nxt, tau, lo, lo + edge, pack_lower=down)
