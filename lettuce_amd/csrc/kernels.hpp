@@ -964,12 +964,12 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   int r = 1, r3 = 1;                                // output plane k has relative index k - s + 1
   for (int k = s; k < last; ++k) {
     lds_barrier();                                  // planes up to k + 1 complete; reads of k - 1 done
-    read_b(r, r3);
-    collide_b();
+    read_b(r, r3);                                  // 19 LDS reads in flight ...
     if (k + 2 <= last) {
-      compute_a(r + 2, r3 == 0 ? 2 : r3 - 1);       // (r + 2) % 3
+      compute_a(r + 2, r3 == 0 ? 2 : r3 - 1);       // ... behind the collide of plane k + 2; (r + 2) % 3
       if (k + 3 <= last) load_a(k + 3);
     }
+    collide_b();
     store_b(k);
     ++r;
     r3 = r3 == 2 ? 0 : r3 + 1;
