@@ -620,3 +620,25 @@ def test_lt_run_uses_many_step_launches_on_small_2d_grids():
         assert info["many_step_launches"] == (0 if mode == 0 else 3)       # 19 fused steps = 8 + 8 + 3
         outs.append((r.clone(), other.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("lat,dt,res", [("D3Q19", "f32", [256, 256, 256]), ("D3Q19", "f64", [384, 384, 96]),
+                                        ("D3Q27", "f32", [256, 256, 128])],
+                         ids=["cfg2-shape", "cfg5-shape", "d3q27"])
+def test_two_step_path_full_size_long_run_is_bit_identical_to_the_one_step_path(lat, dt, res):
+    """BASELINE-size grids, 201 steps through lt_run with and without paired steps: any race on the
+    LDS planes or any addressing slip of the two-step kernel would show as a difference."""
+    L = orc.LATTICES[lat]
+    torch.manual_seed(0)
+    w = torch.rand(L.q, 1, 1, 1, device="cuda", dtype=TORCH_DT[dt]) * 0.03 + 0.02
+    f0 = (w * (1 + 0.05 * torch.rand([L.q] + res, device="cuda", dtype=TORCH_DT[dt]))).contiguous()
+    outs = []
+    for mode in (0, 1):
+        plan = plan_for(lat, TORCH_DT[dt], "bgk", res)
+        plan.set_two_step(mode)
+        r, other = plan.run(f0.clone(), torch.empty_like(f0), 0.55, 201)
+        assert plan.last_run_info()["two_step_launches"] == 100 * mode
+        outs.append(r.clone())
+        del plan, r, other
+    assert torch.equal(outs[0], outs[1])
+    assert bool(torch.isfinite(outs[1]).all())
