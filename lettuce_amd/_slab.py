@@ -463,6 +463,15 @@ class TwoStepSlabSimulation(SlabSimulation):
         # 0.367 ms per step with peer windows -- no reason to delay the exchange.
         self.edge_planes = max(2, int(os.environ.get("LT_SLAB_EDGE_PLANES", "2")))
         super().__init__(flow, collision, slab, **kwargs)
+        # A two-step workgroup holds a CU's LDS for its whole segment, and RCCL's copy kernel needs
+        # LDS of its own: beside one long interior segment per CU it starts only when the first
+        # workgroups retire.  Shorter segments let it in earlier: a quarter of the interior planes
+        # (15 of 60) measured 0.357 vs 0.369 ms/step in the self-exchange rehearsal, 10 and 6 planes
+        # are slower again (0.371, 0.392); LT_SLAB_RCCL_SEGMENT overrides, 0 = the engine's choice.
+        interior = self.hi - self.lo - 2 * self.edge_planes
+        seg = int(os.environ.get("LT_SLAB_RCCL_SEGMENT", str(interior // 4 if interior >= 32 else 0)))
+        if seg > 0 and self._window is None and hasattr(self.engine, "set_two_step"):
+            self.engine.set_two_step(1, seg)
 
     def _message_blocks(self, stencil) -> int:
         e = np.array(stencil.e)
