@@ -191,9 +191,13 @@ def main():
 
         def build(driver, transport):
             flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 1600, 0.1, lt.D3Q19(), slab=slab)
-            cls = lt.TwoStepSlabSimulation if driver == "two-step" else lt.SlabSimulation
-            return cls(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
-                       overlap=not args.no_overlap, transport=transport)
+            coll = lt.BGKCollision(flow.units.relaxation_parameter_lu)
+            if driver == "two-step":
+                # "window-fused": edge launches store into the neighbour's window themselves, one stream
+                return lt.TwoStepSlabSimulation(flow, coll, slab, overlap=not args.no_overlap,
+                                                transport=transport.split("-")[0],
+                                                fused_remote_pack=transport.endswith("-fused"))
+            return lt.SlabSimulation(flow, coll, slab, overlap=not args.no_overlap, transport=transport)
 
         def all_ranks(flag: bool) -> bool:
             t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
@@ -209,6 +213,8 @@ def main():
         transports = ["rccl", "window"] if args.transport == "auto" else [args.transport]
         drivers = ["two-step", "single-step"] if args.driver == "auto" else [args.driver]
         wanted = [(d, t) for d in drivers for t in transports]
+        if "two-step" in drivers and "window" in transports:
+            wanted.insert(wanted.index(("two-step", "window")) + 1, ("two-step", "window-fused"))
         if args.driver == "auto" and args.transport == "auto":
             wanted = [("single-step", "rccl")] + [w for w in wanted if w != ("single-step", "rccl")]
         finals, probe = {}, {}
@@ -216,7 +222,7 @@ def main():
         probe_steps = max(args.warmup, 60)
         for driver, transport in wanted:
             name = f"{driver}/{transport}"
-            if transport == "window":
+            if transport.startswith("window"):
                 if window_ok is None:
                     # preflight on every rank before the collective rendezvous inside build(): a rank
                     # that cannot allocate peer-mappable memory must not leave the others waiting
@@ -278,7 +284,8 @@ def main():
         kernel = sim.engine.kernel_name()
         step = sim
         how = ("RCCL send/recv ghost planes" if transport == "rccl"
-               else "one-sided ghost-plane stores into peer windows (xGMI peer access)")
+               else "one-sided ghost-plane stores into peer windows (xGMI peer access)"
+               + (", issued by the edge launches" if transport.endswith("-fused") else ""))
         how += ("; two lattice updates per launch, one exchange per two updates" if driver == "two-step"
                 else "; one exchange per update")
         parallelism = f"z-slab x{world}, {how}" + ("" if not args.no_overlap else " (no overlap)")

@@ -451,9 +451,19 @@ class TwoStepSlabSimulation(SlabSimulation):
     # With windows the exchange could ride on the compute stream (stores + signal before the interior
     # launch, wait + unpack after it); on one GPU that is 1.5 % faster, but across xGMI the pack
     # launch takes as long as the transfer and would delay the interior launch: two streams.
-    ONE_STREAM_WINDOWS = os.environ.get("LT_SLAB_ONE_STREAM") == "1"
+    ONE_STREAM_WINDOWS = False
 
-    def __init__(self, flow, collision, slab: ZSlab, **kwargs):
+    def __init__(self, flow, collision, slab: ZSlab, fused_remote_pack: Optional[bool] = None, **kwargs):
+        """``fused_remote_pack`` (window transport only): True = the edge launches store the halo
+        message into the neighbour's window themselves and the whole exchange rides on the compute
+        stream; False (default, see ``_edges``) = a separate pack launch on the communication
+        stream.  None reads LT_SLAB_FUSED_REMOTE_PACK / LT_SLAB_ONE_STREAM."""
+        if fused_remote_pack is None:
+            self._fused_remote = os.environ.get("LT_SLAB_FUSED_REMOTE_PACK") == "1"
+            self.ONE_STREAM_WINDOWS = os.environ.get("LT_SLAB_ONE_STREAM") == "1"
+        else:
+            self._fused_remote = bool(fused_remote_pack)
+            self.ONE_STREAM_WINDOWS = bool(fused_remote_pack)
         if flow.boundaries:
             raise LettuceException("the two-step slab driver handles periodic flows only")
         if slab.nz_local < 4:
@@ -527,9 +537,9 @@ class TwoStepSlabSimulation(SlabSimulation):
         # Fused packing only into local send buffers.  With peer windows the message is 20 MB of
         # stores over one xGMI link per direction (~0.3-0.4 ms): inside the edge launch they would
         # hold all CUs (one workgroup per CU, 150 KB of LDS) for that long, so a separate light pack
-        # launch does them beside the interior launch instead (LT_SLAB_FUSED_REMOTE_PACK=1 to A/B;
-        # on one GPU, where the "remote" stores are local, fusing is 2 % faster).
-        fuse = self._window is None or os.environ.get("LT_SLAB_FUSED_REMOTE_PACK") == "1"
+        # launch does them beside the interior launch instead (fused_remote_pack=True to A/B; on
+        # one GPU, where the "remote" stores are local, fusing is 2 % faster; bench.py times both).
+        fuse = self._window is None or self._fused_remote
         if fuse and hasattr(eng, "stream_collide_twice_planes_packed"):
             down, up = ((self._send_down, self._send_up) if self._window is None
                         else self._window.targets())
