@@ -782,16 +782,17 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename T, class S, int LAYOUT, int COLL, int T0_, int T1, int NPT = 1, bool PACK = false>
+template <typename T, class S, int LAYOUT, int COLL, int T0_, int T1, int NPT = 1, bool PACK = false,
+          int NPB = NPT>
 __global__ void __launch_bounds__(((TwoStep<T, S, T0_, T1>::NI / NPT + 63) / 64 * 64))
 lbm2_kernel(const KParams<T> p, const int seg_len) {
-  // NPT nodes per thread (1 or 2): thread t owns intermediate nodes t + k NA and output nodes
-  // t + k NB, k < NPT
+  // NPT intermediate nodes and NPB output nodes per thread (1 or 2): thread t owns intermediate
+  // nodes t + k NA, k < NPT, and output nodes t + k NB, k < NPB
   using B = TwoStep<T, S, T0_, T1>;
   using M = MemMap<S, LAYOUT>;
   constexpr int T0 = B::T0, H0 = B::H0, NI = B::NI, NO = B::NO;
-  constexpr int NA = NI / NPT, NB = NO / NPT;
-  static_assert(NI % NPT == 0 && NO % NPT == 0, "nodes per thread must divide the tile");
+  constexpr int NA = NI / NPT, NB = NO / NPB;
+  static_assert(NI % NPT == 0 && NO % NPB == 0, "nodes per thread must divide the tile");
   constexpr int NU = B::template count<LAYOUT, 1>(), NC = B::template count<LAYOUT, 0>(),
                 ND = B::template count<LAYOUT, -1>();
   static_assert(COLL == 0 || COLL == 1, "two-step kernel: streaming only or BGK");
@@ -814,9 +815,9 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   // Addresses: the plane part is uniform (scalar registers, recomputed per plane), the in-plane
   // part is a per-thread constant -- nine byte offsets for the nine (e0, e1) pairs of the lattice.
   unsigned voff[NPT][3][3];                          // [k][e1 + 1][e0 + 1], bytes within a plane
-  unsigned out_off[NPT];
+  unsigned out_off[NPB];
   int a_at[NPT];                                     // LDS index of the intermediate node
-  int b_at[NPT];                                     // LDS index of the output node incl. halo offset
+  int b_at[NPB];                                     // LDS index of the output node incl. halo offset
   static_for<NPT>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
     // phase A: node (i0, i1) of the halo'd tile, global coordinates (g0, g1).  The T0 inner columns
@@ -844,6 +845,9 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
         const int x = c == 0 ? g0p : (c == 1 ? g0 : g0m);
         voff[k][a][c] = ((unsigned)y * (unsigned)p.n0 + (unsigned)x) * (unsigned)sizeof(T);
       }
+  });
+  static_for<NPB>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
     // phase B: output node (j0, j1) of the tile
     const int ib = tid + k * NB;
     const int j1 = ib / T0, j0 = ib - j1 * T0;
@@ -892,13 +896,13 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
       });
     }
   };
-  T f[S::Q][NPT];
+  T f[S::Q][NPB];
   auto read_b = [&](int r, int r3) {                 // output plane with relative index r
     if (in_b) {
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1), e2 = M::e(q, 2), rank = crossing_rank<S, LAYOUT, q>();
-        static_for<NPT>([&](auto kc) {
+        static_for<NPB>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
           const int at = b_at[k] - e1 * H0 - e0;
           if constexpr (e2 > 0) f[q][k] = lds_u[(r - 1) & 3][rank][at];
@@ -911,7 +915,7 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   auto collide_b = [&]() {
     if (in_b) {
       if constexpr (COLL == 1)
-        static_for<NPT>([&](auto kc) { collide_bgk<T, S, LAYOUT, NPT, decltype(kc)::value>(f, p.tau_inv); });
+        static_for<NPB>([&](auto kc) { collide_bgk<T, S, LAYOUT, NPB, decltype(kc)::value>(f, p.tau_inv); });
     }
   };
   auto store_b = [&](int k2) {
@@ -919,7 +923,7 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         T *base = p.out + ((long long)q * p.N + (long long)((unsigned)k2 * plane_nodes));
-        static_for<NPT>([&](auto kc) {
+        static_for<NPB>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
           __builtin_nontemporal_store(f[q][k], reinterpret_cast<T *>(reinterpret_cast<char *>(base) + out_off[k]));
         });
@@ -933,7 +937,7 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
           if (d == 0 || (d == 1 && e2 < 0)) {
             const int slot = e2 == 0 ? rank : (d == 0 ? NC + rank : NC + ND + rank);
             T *msg = p.pack_lo + (size_t)slot * plane_nodes;
-            static_for<NPT>([&](auto kc) {
+            static_for<NPB>([&](auto kc) {
               constexpr int k = decltype(kc)::value;
               *reinterpret_cast<T *>(reinterpret_cast<char *>(msg) + out_off[k]) = f[q][k];
             });
@@ -944,7 +948,7 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
           if (d == 0 || (d == 1 && e2 > 0)) {
             const int slot = e2 == 0 ? rank : (d == 0 ? NC + rank : NC + NU + rank);
             T *msg = p.pack_hi + (size_t)slot * plane_nodes;
-            static_for<NPT>([&](auto kc) {
+            static_for<NPB>([&](auto kc) {
               constexpr int k = decltype(kc)::value;
               *reinterpret_cast<T *>(reinterpret_cast<char *>(msg) + out_off[k]) = f[q][k];
             });

@@ -38,7 +38,7 @@ plan = Plan("D3Q19", torch.float32, "bgk", res, [], device=torch.device("cuda:0"
 f = torch.rand(plan.f_shape, device="cuda") * 0.01 + 0.05
 g = torch.empty_like(f)
 out = {}
-variants = [("single", -1, 0)] + [(f"v{v}_seg{seg}", seg, v) for v in (0, 1) for seg in (64, 128)]
+variants = [("single", -1, 0)] + [(f"v{v}_seg{seg}", seg, v) for v in (0, 2) for seg in (64, 128)]
 for r in range(5):
     for label, seg, variant in variants:
         if seg > 0:
