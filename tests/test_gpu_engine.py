@@ -587,7 +587,7 @@ def test_two_step_edge_launch_writes_the_same_halo_message_as_the_pack_kernel():
 
 # --------------------------------------------------------------------------- many steps per launch (2-D)
 @pytest.mark.parametrize("res", [[8, 8], [16, 24], [128, 128], [40, 8]])
-@pytest.mark.parametrize("coll,dt", [("bgk", "f64"), ("bgk", "f32"), ("none", "f32"), ("kbc", "f64")])
+@pytest.mark.parametrize("coll,dt", [("bgk", "f64"), ("bgk", "f32"), ("none", "f32"), ("kbc", "f64"), ("kbc", "f32")])
 def test_many_steps_per_launch_equal_single_steps(res, coll, dt):
     """lt_stream_collide_many (K <= 8 steps in LDS, recomputed halo, neighbourhoods that wrap around
     tiny grids several times) against K lt_stream_collide launches, every K."""
@@ -601,7 +601,10 @@ def test_many_steps_per_launch_equal_single_steps(res, coll, dt):
         a, b = b, a
         got = torch.empty_like(f)
         plan.stream_collide_many(f, got, 0.7, k)
-        assert torch.equal(got, a), k
+        if coll == "kbc":      # KBC may contract multiply-adds differently in the two kernels: rounding level
+            assert float((got - a).abs().max()) <= (1e-6 if dt == "f32" else 1e-14) * float(a.abs().max()), k
+        else:
+            assert torch.equal(got, a), k
 
 
 def test_lt_run_uses_many_step_launches_on_small_2d_grids():
