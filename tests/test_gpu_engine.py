@@ -602,7 +602,7 @@ def test_many_steps_per_launch_equal_single_steps(res, coll, dt):
         got = torch.empty_like(f)
         plan.stream_collide_many(f, got, 0.7, k)
         if coll == "kbc":      # KBC may contract multiply-adds differently in the two kernels: rounding level
-            assert float((got - a).abs().max()) <= (1e-6 if dt == "f32" else 1e-14) * float(a.abs().max()), k
+            assert float((got - a).abs().max()) <= (1e-5 if dt == "f32" else 1e-13) * float(a.abs().max()), k
         else:
             assert torch.equal(got, a), k
 
