@@ -261,7 +261,8 @@ int lt_stream_collide_twice(lt_plan *plan, const void *f_dev, void *out_dev, dou
  * redundant arithmetic but replaces n_steps launches; bit-identical to n_steps lt_stream_collide
  * calls.  2-D lattices, no masks, extents multiples of 8; LT_ERR_UNSUPPORTED otherwise.
  * lt_plan_set_many_step: lt_run / lt_continue use it for their fused steps: -1 = automatic (grids up
- * to 256 x 256 nodes), 0 = never, 1 = whenever supported. */
+ * to 256 x 256 nodes, BGK / no collision, where it is bit-identical to the one-step kernel),
+ * 0 = never, 1 = whenever supported. */
 int lt_stream_collide_many(lt_plan *plan, const void *f_dev, void *out_dev, double tau, int32_t n_steps,
                            void *stream);
 int lt_plan_set_many_step(lt_plan *plan, int32_t mode);

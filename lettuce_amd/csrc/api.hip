@@ -437,6 +437,10 @@ bool many_step_wanted(lt_plan *p) {
   a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = lt::kFusedMany;
   if (!p->unit.name(a)) return false;
   if (p->many == 1) return true;
+  // automatic only where the many-step kernel is bit-identical to the one-step kernel, so that the
+  // result of n steps does not depend on how the caller splits them into batches (KBC agrees at
+  // rounding level only)
+  if (p->desc.collision == LT_COLLISION_KBC) return false;
   return p->N <= 256ll * 256ll;
 }
 
