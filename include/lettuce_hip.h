@@ -187,6 +187,11 @@ int lt_stream_collide_twice_planes(lt_plan *plan, const void *f_dev, void *out_d
 int lt_stream_collide_twice_planes_packed(lt_plan *plan, const void *f_dev, void *out_dev, double tau,
                                           int64_t begin, int64_t end, void *pack_lower_dev,
                                           void *pack_upper_dev, void *stream);
+/* The two edges of a slab in ONE launch: output planes [2, 2 + edge_planes) and
+ * [n2 - 2 - edge_planes, n2 - 2), optionally writing both halo messages (both buffers or neither). */
+int lt_stream_collide_twice_edges(lt_plan *plan, const void *f_dev, void *out_dev, double tau,
+                                  int32_t edge_planes, void *pack_lower_dev, void *pack_upper_dev,
+                                  void *stream);
 int lt_slab_pack_two_step(lt_plan *plan, const void *f_dev, int32_t side, void *buf_dev, void *stream);
 int lt_slab_unpack_two_step(lt_plan *plan, void *f_dev, int32_t side, const void *buf_dev, void *stream);
 

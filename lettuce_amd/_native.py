@@ -93,6 +93,7 @@ SYMBOLS = {
     "lt_plan_set_two_step": (ctypes.c_int, [_vp, _i32, _i32]),
     "lt_stream_collide_twice_planes": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _i64, _vp]),
     "lt_stream_collide_twice_planes_packed": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _i64, _vp, _vp, _vp]),
+    "lt_stream_collide_twice_edges": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i32, _vp, _vp, _vp]),
     "lt_slab_pack_two_step": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "lt_slab_unpack_two_step": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "lt_plan_set_fused_events": (ctypes.c_int, [_vp, _vp, _vp]),
@@ -489,6 +490,12 @@ class Plan:
         self._check(self.lib.lt_stream_collide_twice_planes_packed(
             self._handle, _ptr(f), _ptr(out), float(tau), int(begin), int(end), _ptr(pack_lower),
             _ptr(pack_upper), _stream_handle()))
+
+    @_on_device
+    def stream_collide_twice_edges(self, f, out, tau, edge_planes, pack_lower=None, pack_upper=None):
+        self._check(self.lib.lt_stream_collide_twice_edges(
+            self._handle, _ptr(f), _ptr(out), float(tau), int(edge_planes), _ptr(pack_lower), _ptr(pack_upper),
+            _stream_handle()))
 
     @_on_device
     def pack_two_step(self, f, side, buf):

@@ -540,6 +540,17 @@ class TwoStepSlabSimulation(SlabSimulation):
         # launch does them beside the interior launch instead (fused_remote_pack=True to A/B; on
         # one GPU, where the "remote" stores are local, fusing is 2 % faster; bench.py times both).
         fuse = self._window is None or self._fused_remote
+        # One launch for both edges (lt_stream_collide_twice_edges) measured no better (RCCL, fused
+        # windows) or worse (separate pack on two streams: 0.389 vs 0.348 ms/step -- the bigger launch
+        # competes with the interior launch for CUs and delays the exchange): two launches.
+        if hasattr(eng, "stream_collide_twice_edges") and os.environ.get("LT_SLAB_MERGED_EDGES") == "1":
+            if fuse:
+                down, up = ((self._send_down, self._send_up) if self._window is None
+                            else self._window.targets())
+                eng.stream_collide_twice_edges(cur, nxt, tau, edge, pack_lower=down, pack_upper=up)
+            else:
+                eng.stream_collide_twice_edges(cur, nxt, tau, edge)
+            return fuse
         if fuse and hasattr(eng, "stream_collide_twice_planes_packed"):
             down, up = ((self._send_down, self._send_up) if self._window is None
                         else self._window.targets())

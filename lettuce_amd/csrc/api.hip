@@ -82,6 +82,7 @@ struct lt_plan {
   int seg_len = 0;           // planes per workgroup of the two-step kernel, 0 = automatic
   int many = -1;             // lt_run: several steps per launch on small 2-D grids: -1 = automatic, 0 / 1
   int many_now = 1;          // steps of the kFusedMany launch being issued
+  long long second_begin = 0, second_end = 0;   // second plane range of the kFusedTwice launch being issued
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // lt_plan_set_fused_events
   long long last_single = 0, last_twice = 0, last_many = 0;   // fused launches of the last lt_run
   int want_wide = 0;         // 16-byte accesses for the hot kernel (A/B experiments)
@@ -344,6 +345,11 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.stream = static_cast<hipStream_t>(stream);
   a.pack_lo = pack_lo; a.pack_hi = pack_hi;
   a.pack_lo_plane = (int)pb; a.pack_hi_plane = (int)(pb + stride * (a.planes - 1));
+  if (mode == lt::kFusedTwice) {
+    a.p_begin2 = (int)p->second_begin;
+    a.planes2 = (int)(p->second_end - p->second_begin);
+    if (a.planes2 > 0) a.pack_hi_plane = (int)p->second_end - 1;   // upper message: last plane of the second range
+  }
   const int r = p->unit.step(a);
   if (r == lt::kNoKernel)
     return fail(LT_ERR_UNSUPPORTED, "no kernel for layout %d collision %d mode %d masked %d",
@@ -814,6 +820,23 @@ int lt_stream_collide_twice_planes_packed(lt_plan *p, const void *f, void *out, 
   if (pack_upper && end != p->n2 - 2)
     return fail(LT_ERR_INVALID, "upper message: the range must end at the last interior plane");
   return step(p, lt::kFusedTwice, f, out, tau, begin, end, stream, 1, pack_lower, pack_upper);
+}
+int lt_stream_collide_twice_edges(lt_plan *p, const void *f, void *out, double tau, int32_t edge_planes,
+                                  void *pack_lower, void *pack_upper, void *stream) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (p->desc.ghost_planes != 2) return fail(LT_ERR_INVALID, "edge launch needs ghost_planes = 2");
+  const long long lo = 2, hi = p->n2 - 2;
+  if (edge_planes < 2 || 2ll * edge_planes > hi - lo)
+    return fail(LT_ERR_INVALID, "edge_planes = %d (2 .. %lld)", edge_planes, (hi - lo) / 2);
+  if ((pack_lower == nullptr) != (pack_upper == nullptr))
+    return fail(LT_ERR_INVALID, "give both message buffers or neither");
+  p->second_begin = hi - edge_planes; p->second_end = hi;
+  const int saved = p->seg_len;
+  p->seg_len = edge_planes;                       // one segment per range and tile
+  const int rc = step(p, lt::kFusedTwice, f, out, tau, lo, lo + edge_planes, stream, 1, pack_lower, pack_upper);
+  p->seg_len = saved;
+  p->second_begin = p->second_end = 0;
+  return rc;
 }
 int lt_slab_pack_two_step(lt_plan *p, const void *f, int32_t side, void *buf, void *s) {
   return halo2(p, true, const_cast<void *>(f), side, buf, s);

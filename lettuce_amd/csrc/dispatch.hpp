@@ -14,6 +14,7 @@ struct StepArgs {
   int n0, n1, n2;        // memory extents (n2 incl. ghost planes)
   int p_begin, planes;   // a2 planes of this launch: p_begin + i * p_stride, i < planes
   int p_stride;
+  int p_begin2, planes2;  // kFusedTwice: optional second range of output planes
   int wrap2;
   double tau;
   const unsigned char *node;

@@ -54,6 +54,7 @@ struct KParams {
   int nv0;                   // n0 / VEC
   int p_begin;               // first a2 plane of this launch
   int p_end;                 // two-step kernel: one past the last output plane
+  int p_begin2, p_end2;      // two-step kernel: optional second range of output planes (slab edges)
   int p_stride;              // distance between consecutive planes of this launch (normally 1)
   int wrap2;                 // periodic wrap along a2 (0 with ghost planes)
   long long N;               // n0*n1*n2 = stride between populations
@@ -809,7 +810,11 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   if (p.nb == 0 && gridDim.x % 8 == 0) b = (b % 8) * (gridDim.x / 8) + b / 8;
   const int t0 = (b % tiles0) * T0; b /= tiles0;
   const int t1 = (b % tiles1) * T1; b /= tiles1;
-  const int s = p.p_begin + b * seg_len;           // first output plane of this workgroup
+  // first output plane of this workgroup: segments of the first range, then of the second one
+  const int segs_a = (p.p_end - p.p_begin + seg_len - 1) / seg_len;
+  const bool second = b >= segs_a;
+  const int range_end = second ? p.p_end2 : p.p_end;
+  const int s = second ? p.p_begin2 + (b - segs_a) * seg_len : p.p_begin + b * seg_len;
 
   const bool in_a = tid < NA, in_b = tid < NB;
   // Addresses: the plane part is uniform (scalar registers, recomputed per plane), the in-plane
@@ -960,7 +965,7 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   };
 
   // intermediate planes s-1 .. s+seg_len are needed (relative indices 0 .. seg_len+1)
-  const int last = s + seg_len < p.p_end ? s + seg_len : p.p_end;
+  const int last = s + seg_len < range_end ? s + seg_len : range_end;
   load_a(s - 1); compute_a(0, 0);
   load_a(s);     compute_a(1, 1);
   load_a(s + 1); compute_a(2, 2);

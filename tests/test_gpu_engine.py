@@ -645,3 +645,28 @@ def test_two_step_path_full_size_long_run_is_bit_identical_to_the_one_step_path(
         del plan, r, other
     assert torch.equal(outs[0], outs[1])
     assert bool(torch.isfinite(outs[1]).all())
+
+
+def test_both_slab_edges_in_one_launch_with_and_without_messages():
+    from lettuce_amd._native import Plan, LAYOUT_SLAB
+    plan = Plan("D3Q19", torch.float32, "bgk", [64, 16, 14], [], layout=LAYOUT_SLAB, ghost_planes=2)
+    torch.manual_seed(29)
+    f = (0.05 + 0.01 * torch.rand(plan.f_shape, device="cuda")).contiguous()
+    n2 = f.shape[1]
+    ref = torch.zeros_like(f)
+    plan.stream_collide_twice_planes(f, ref, 0.7, 2, n2 - 2)
+    want_down, want_up = torch.empty([19, 16, 64], device="cuda"), torch.empty([19, 16, 64], device="cuda")
+    plan.pack_two_step(ref, -1, want_down)
+    plan.pack_two_step(ref, +1, want_up)
+    for edge in (2, 3, 5):
+        for packed in (False, True):
+            out = torch.zeros_like(f)
+            down, up = torch.zeros_like(want_down), torch.zeros_like(want_up)
+            if packed:
+                plan.stream_collide_twice_edges(f, out, 0.7, edge, pack_lower=down, pack_upper=up)
+                assert torch.equal(down, want_down) and torch.equal(up, want_up)
+            else:
+                plan.stream_collide_twice_edges(f, out, 0.7, edge)
+            assert torch.equal(out[:, 2:2 + edge], ref[:, 2:2 + edge])
+            assert torch.equal(out[:, n2 - 2 - edge:n2 - 2], ref[:, n2 - 2 - edge:n2 - 2])
+            assert float(out[:, 2 + edge:n2 - 2 - edge].abs().max()) == 0.0      # interior untouched
