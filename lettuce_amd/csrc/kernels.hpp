@@ -757,14 +757,17 @@ __global__ void __launch_bounds__(kThreads, 4) lbm_kernel_occ4(const KParams<T> 
 // only from plane k and those moving down ("D") only from plane k+1.  With 4 LDS slots for U, 3 for
 // C and 2 for D -- 57 population planes, as many as three whole planes -- A(k+2) can write while
 // other waves still read for B(k), and ONE barrier per plane is enough:
-//   barrier; LDS reads of B(k); collide B(k); collide A(k+2) -> LDS; issue the global loads of
-//   A(k+3) (they land during the next plane); store B(k).
-// The barrier waits for LDS traffic only (an ordinary __syncthreads() would drain the prefetch), and
-// all global-memory instructions of a plane are issued together at its end, loads first, so that
-// the vmcnt waits in front of A never meet stores issued just before them.
+//   barrier; issue the LDS reads of B(k); collide A(k+2) -> LDS (the reads fly behind it); issue
+//   the global loads of A(k+3) (they land during the next plane); collide B(k); store B(k).
+// The barrier waits for LDS traffic only (an ordinary __syncthreads() would drain the prefetch); the
+// loads are issued as early as the registers allow and before the stores, so that the vmcnt waits
+// in front of the next A never meet stores issued just before them.  The order was found by
+// measurement: each of these placements is worth 3-10 %.
 // Arithmetic per node is the one-step kernel's (same pull, same collide): results are bit for bit
 // those of two lbm_kernel launches.  Redundant work: (T0+2)(T1+2)/(T0 T1) in the first step and
-// two extra planes per segment.  HBM traffic (PMC, 256^3): reads 1.13x one pass, writes 1.00x.
+// two extra planes per segment.  HBM traffic (PMC, 256^3): reads 1.05x one pass, writes 1.00x.
+// NPT / NPB: intermediate / output nodes per thread (A/B variants, 1 is the product setting);
+// PACK: slab edge launches that also write the halo message.
 template <typename T, class S, int T0_, int T1>
 struct TwoStep {
   static constexpr int T0 = T0_, H0 = T0 + 2, H1 = T1 + 2;
