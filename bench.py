@@ -344,8 +344,9 @@ def main():
 
     passes = "1 collide + (K-1) fused stream-collide + 1 stream"
     if not distributed and args.steps > 1 and roofline.get("lattice_updates_per_launch", 0) > nodes_per_rank:
-        passes = ("1 collide + (K-1) fused stream-collide steps as two-step launches (+1 single when "
-                  "K-1 is odd) + 1 stream")
+        # the timed call continues from the post-collision state the warm-up call left (lt_continue)
+        passes = ("K fused stream-collide steps as K/2 two-step launches (+1 single when K is odd) + 1 stream, "
+                  "continuing from the post-collision populations of the warm-up batch")
     if rank == 0:
         line = {
             "metric": "MLUPS (million lattice updates/s) D3Q19 256\u00b3 TGV; achieved HBM GB/s vs peak",

@@ -113,9 +113,9 @@ class _NativeStepper:
                          device=ctx.device)
         self._mask_state = None
         self._carry = None      # state that allows lt_continue
-        # optional (start, end) torch.cuda.Event pair: when set, a batch is issued as separate
-        # collide / fused... / stream calls with the events recorded around the fused launches
-        # (bench.py times the dominant kernel live with them)
+        # optional (start, end) torch.cuda.Event pair: when set, lt_run / lt_continue record them on
+        # the launch stream around the fused launches of a batch (lt_plan_set_fused_events;
+        # bench.py times the dominant kernel live with them, plan.last_run_info() says what they bracket)
         self.fused_events = None
 
     # ---- masks -------------------------------------------------------------------------------
@@ -182,24 +182,19 @@ class _NativeStepper:
         tau = float(self.collision.tau(flow))
         f, nxt = self._state_buffers()
         token = (_version(f), _version(nxt), tau)
+        carry = self._carry is not None and self._carry == token
         if self.fused_events is not None:
-            result, other = self._batch_with_events(f, nxt, tau, k)
-        elif self._carry is not None and self._carry == token:
-            result, other = self.plan.run(nxt, f, tau, k, from_fstar=True)
-        else:
-            result, other = self.plan.run(f, nxt, tau, k)
+            self.plan.set_fused_events(*self.fused_events)    # recorded by lt_run around its fused launches
+        try:
+            if carry:
+                result, other = self.plan.run(nxt, f, tau, k, from_fstar=True)
+            else:
+                result, other = self.plan.run(f, nxt, tau, k)
+        finally:
+            if self.fused_events is not None:
+                self.plan.set_fused_events(None, None)
         flow.f, flow.f_next = result, other
         self._carry = (_version(result), _version(other), tau)
-
-    def _batch_with_events(self, f, nxt, tau, k):
-        """lt_run with the event pair recorded by the engine around its fused launches on the
-        launch stream (lt_plan_set_fused_events); ``last_run_info`` tells what they bracket."""
-        start, end = self.fused_events
-        self.plan.set_fused_events(start, end)
-        try:
-            return self.plan.run(f, nxt, tau, k)
-        finally:
-            self.plan.set_fused_events(None, None)
 
     def single_step(self, *_, **__):
         self.batch(1)
