@@ -670,3 +670,41 @@ def test_both_slab_edges_in_one_launch_with_and_without_messages():
             assert torch.equal(out[:, 2:2 + edge], ref[:, 2:2 + edge])
             assert torch.equal(out[:, n2 - 2 - edge:n2 - 2], ref[:, n2 - 2 - edge:n2 - 2])
             assert float(out[:, 2 + edge:n2 - 2 - edge].abs().max()) == 0.0      # interior untouched
+
+
+def test_two_step_kernel_randomised_shapes_lattices_dtypes_and_ranges():
+    """40 random cases (fixed seed): lattice, dtype, grid, collision, periodic or slab layout with a
+    random sub-range of output planes, segment length -- always bit-identical to two single steps."""
+    import random
+    from lettuce_amd._native import Plan, LAYOUT_SLAB
+    rng = random.Random(2024)
+    for _ in range(40):
+        dt = rng.choice([torch.float32, torch.float64])
+        lat = rng.choice(["D3Q19", "D3Q15"] + (["D3Q27"] if dt == torch.float32 else []))
+        q = int(lat[3:])
+        width = 64 if (4 if dt == torch.float32 else 8) * 3 * q * 660 <= 160 * 1024 else 32
+        n0, n1, n2 = width * rng.randint(1, 3), 8 * rng.randint(1, 4), rng.randint(1, 14)
+        coll = rng.choice(["none", "bgk"])
+        slab = rng.random() < 0.4 and n2 >= 3
+        plan = (Plan(lat, dt, coll, [n0, n1, n2], [], layout=LAYOUT_SLAB, ghost_planes=2) if slab
+                else Plan(lat, dt, coll, [n2, n1, n0], []))
+        seg = rng.choice([0, 1, 2, 3, 5])
+        if seg and not slab and n2 % seg:
+            seg = 0
+        plan.set_two_step(1, seg)
+        f = (torch.rand(plan.f_shape, device="cuda", dtype=dt) * 0.01 + 0.04).contiguous()
+        a, b, c = torch.zeros_like(f), torch.zeros_like(f), torch.zeros_like(f)
+        case = (lat, str(dt), [n0, n1, n2], coll, slab, seg)
+        if slab:
+            m = f.shape[1]
+            plan.stream_collide_planes(f, a, 0.7, 1, m - 1)
+            plan.stream_collide_planes(a, b, 0.7, 2, m - 2)
+            lo = rng.randint(2, m - 3)
+            hi = rng.randint(lo + 1, m - 2)
+            plan.stream_collide_twice_planes(f, c, 0.7, lo, hi)
+            assert torch.equal(b[:, lo:hi], c[:, lo:hi]), case
+        else:
+            plan.stream_collide(f, a, 0.7)
+            plan.stream_collide(a, b, 0.7)
+            plan.stream_collide_twice(f, c, 0.7)
+            assert torch.equal(b, c), case
