@@ -230,10 +230,14 @@ int resolve_lds(const lt_plan *p, long long workgroups) {
   return per_wg > 65536 ? 65536 : per_wg;
 }
 
-// contiguous extent of the two-step tile (the rule of unit.inc), 0 = no two-step kernel
-int two_step_tile(const lt_plan *p) {
+// the two-step tile (the rule of unit.inc): rows of 256 bytes, 8 or 4 of them; rows = 0: no kernel
+struct TwoStepTile { int width, rows; };
+TwoStepTile two_step_tile(const lt_plan *p) {
   const long long per_node = (long long)p->esize * 3 * p->unit.q;
-  return per_node * 66 * 10 <= 160 * 1024 ? 64 : (per_node * 34 * 10 <= 160 * 1024 ? 32 : 0);
+  const int width = 256 / p->esize;
+  const int rows = per_node * (width + 2) * 10 <= 160 * 1024
+                       ? 8 : (p->esize == 4 && per_node * (width + 2) * 6 <= 160 * 1024 ? 4 : 0);
+  return {width, rows};
 }
 
 // planes per workgroup of the two-step kernel.  One workgroup occupies a CU (150 KB of LDS), so the
@@ -243,8 +247,8 @@ int two_step_tile(const lt_plan *p) {
 // with 32 planes and 0.52 with 256, which leaves half the CUs idle).
 int resolve_seg_len(const lt_plan *p, int planes) {
   if (p->seg_len > 0) return p->seg_len;
-  const int tile = two_step_tile(p) ? two_step_tile(p) : 64;
-  const long long tiles = (long long)(p->n0 / tile) * (p->n1 / 8);
+  const TwoStepTile tile = two_step_tile(p);
+  const long long tiles = (long long)(p->n0 / tile.width) * (p->n1 / (tile.rows ? tile.rows : 8));
   const long long cus = p->n_cu > 0 ? p->n_cu : 256;
   int best = 1;
   double best_score = -1.0;
@@ -419,8 +423,8 @@ long long run_graph(lt_plan *p, void *cur, void *other, double tau, long long fu
 // asks for the streaming regime (populations beyond the caches), where halving the HBM passes pays.
 bool two_step_wanted(lt_plan *p) {
   if (p->two_step == 0 || p->masked || p->desc.ghost_planes) return false;
-  const int tile = two_step_tile(p);
-  if (tile == 0 || p->n0 % tile != 0 || p->n1 % 8 != 0) return false;
+  const TwoStepTile tile = two_step_tile(p);
+  if (tile.rows == 0 || p->n0 % tile.width != 0 || p->n1 % tile.rows != 0) return false;
   lt::StepArgs a;
   memset(&a, 0, sizeof a);
   a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = lt::kFusedTwice;

@@ -477,7 +477,7 @@ def test_two_step_launch_is_bit_identical_to_two_single_steps(res, seg, coll, dt
 
 @pytest.mark.parametrize("lat,dt", [("D3Q15", "f32"), ("D3Q15", "f64"), ("D3Q27", "f32")])
 def test_two_step_launch_on_the_other_lattices(lat, dt):
-    """the kernel is generic in the lattice; the tile is 64 x 8 or 32 x 8 depending on what fits LDS"""
+    """the kernel is generic in the lattice; rows of 256 bytes, 8 or 4 rows per tile depending on LDS"""
     res = [5, 16, 128]
     plan = plan_for(lat, TORCH_DT[dt], "bgk", res)
     torch.manual_seed(23)
@@ -681,8 +681,7 @@ def test_two_step_kernel_randomised_shapes_lattices_dtypes_and_ranges():
     for _ in range(40):
         dt = rng.choice([torch.float32, torch.float64])
         lat = rng.choice(["D3Q19", "D3Q15"] + (["D3Q27"] if dt == torch.float32 else []))
-        q = int(lat[3:])
-        width = 64 if (4 if dt == torch.float32 else 8) * 3 * q * 660 <= 160 * 1024 else 32
+        width = 64 if dt == torch.float32 else 32            # rows of 256 bytes; 8 or 4 rows per tile
         n0, n1, n2 = width * rng.randint(1, 3), 8 * rng.randint(1, 4), rng.randint(1, 14)
         coll = rng.choice(["none", "bgk"])
         slab = rng.random() < 0.4 and n2 >= 3
