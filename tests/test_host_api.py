@@ -332,8 +332,12 @@ def test_bench_finds_the_committed_pmc_traffic_for_the_fused_kernel():
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    name = "lbm_kernel<float, lt::d3q19, 0, 1, true, true, false, 1, 0, 3, false>"
+    # the dominant kernel of the default bench run: two lattice updates per launch, so the HBM bytes
+    # of a launch are about half the algorithmic bytes of the two updates
+    name = "lbm2_kernel<float, lt::d3q19, 0, 1, 64, 8, 1, false, 1>"
     traffic = bench.traffic_from_profile(name)
     assert traffic is not None
-    assert abs(traffic / (152 * 256 ** 3) - 1.0) < 0.02
+    assert 0.45 < traffic / (2 * 152 * 256 ** 3) < 0.6
+    # names that gained trailing template parameters since the profile was taken still match
+    assert bench.traffic_from_profile(name.replace(", 1>", ", 1, 0>")) == traffic
     assert bench.traffic_from_profile("lbm_kernel<float, lt::d3q19, 0, 1, true, true, false, 1, 0, 0, false>") is None
