@@ -707,3 +707,23 @@ def test_two_step_kernel_randomised_shapes_lattices_dtypes_and_ranges():
             plan.stream_collide(a, b, 0.7)
             plan.stream_collide_twice(f, c, 0.7)
             assert torch.equal(b, c), case
+
+
+def test_two_step_slab_reads_only_the_exchanged_populations_of_the_ghost_planes():
+    """Everything in the ghost planes that the two-step halo message does not carry is poisoned with
+    NaN: the output planes must not change (the driver leaves those slots uninitialised)."""
+    from lettuce_amd._native import Plan, LAYOUT_SLAB
+    plan = Plan("D3Q19", torch.float32, "bgk", [64, 16, 9], [], layout=LAYOUT_SLAB, ghost_planes=2)
+    torch.manual_seed(31)
+    f = (0.05 + 0.01 * torch.rand(plan.f_shape, device="cuda")).contiguous()
+    n2 = f.shape[1]
+    ref = torch.zeros_like(f)
+    plan.stream_collide_twice_planes(f, ref, 0.7, 2, n2 - 2)
+    e = np.array(orc.LATTICES["D3Q19"].e)
+    up, inp, down = (np.nonzero(e[:, 2] == v)[0] for v in (1, 0, -1))
+    g = f.clone()
+    g[down, 1] = float("nan"); g[np.concatenate([inp, down]), 0] = float("nan")          # lower ghosts
+    g[up, n2 - 2] = float("nan"); g[np.concatenate([inp, up]), n2 - 1] = float("nan")    # upper ghosts
+    out = torch.zeros_like(f)
+    plan.stream_collide_twice_planes(g, out, 0.7, 2, n2 - 2)
+    assert torch.equal(out[:, 2:n2 - 2], ref[:, 2:n2 - 2])
