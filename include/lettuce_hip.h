@@ -236,8 +236,10 @@ int lt_plan_kernel_info(lt_plan *plan, int32_t *vec_width, int32_t *threads_per_
                         int64_t *blocks_per_launch);
 /* Name of the fused kernel variant this plan launches (for matching rocprof rows). */
 const char *lt_plan_kernel_name(lt_plan *plan);
-/* 16-byte variant only: 0 = aligned vector load + one neighbour element, 1 = unaligned vector
- * load, 2 = aligned vector load + cross-lane shift. */
+/* A/B selector.  16-byte variant of the one-step kernel: 0 = aligned vector load + one neighbour
+ * element, 1 = unaligned vector load, 2 = aligned vector load + cross-lane shift.  Two-step kernel
+ * (D3Q19 / D3Q15 fp32, BGK, reference layout): 0 = product variant, 1 = two nodes per thread in both
+ * phases, 2 = two output nodes per thread, 3 = no XCD-aware renumbering of the workgroups. */
 int lt_plan_set_shift_policy(lt_plan *plan, int32_t policy);
 /* Diagnostic: dst[0:n_bytes] = src[0:n_bytes] with 16-byte accesses and the cache-policy bits of
  * lt_plan_set_tuning; max_blocks > 0 caps its grid (grid-stride loop).  bench.py uses it to
