@@ -14,12 +14,31 @@ A "step" is one full lattice update (collide, stream) of every node.  The timed 
 exactly K steps between barrier + device synchronise, max over ranks; value = all nodes of all
 ranks * K / time.  One JSON line is printed by rank 0.
 
-roofline: HBM-bound kernel.  achieved = algorithmic bytes per launch (2 * 19 * 4 = 152 B per
-node) / average duration of the fused stream-collide launches, measured with
-HIP events recorded on the launch stream around the K-1 fused launches of the timed region.
+Launching.  ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment starts its
+own N ranks (a ``torch.distributed.run`` child process, before this process touches the GPU),
+relays rank 0's JSON line and the exit code; fewer than N visible devices is an error, never a
+silent N = 1 run.  Under a launcher (WORLD_SIZE set) the process is one rank.
+
+Timing.  Five timed batches of exactly K steps each (barrier + device synchronise on both sides,
+max over ranks); ``ms_per_step`` / ``value`` are those of the median batch, all
+five are listed in ``batches_ms_per_step``.
+
+roofline: HBM-bound kernel.  ``achieved`` = the bytes a launch of the dominant kernel has to move
+through HBM -- every population read once and written once, 2 * 19 * 4 = 152 B per node and
+launch, however many lattice updates the launch performs on them -- divided by
+its average duration, measured with HIP events recorded on the launch stream around the fused
+launches of the median batch.  ``frac`` = achieved / 8 TB/s, a physical HBM fraction (<= 1).  The
+two-step kernel does two lattice updates per launch with the intermediate state in LDS; the rate
+in algorithmic bytes of lattice updates (152 B per node and UPDATE) is reported separately as
+``algorithmic_update_GBps`` and may exceed the HBM peak.  ``traffic`` = HBM bytes per launch from
+the rocprofv3 PMC passes in profiles/traffic.json, used only if that file was produced from the
+kernel sources of this build (hash of lettuce_amd/csrc), else null.
+verified: after the timed batches the same 5 K steps are repeated, untimed, from a copy of the
+pre-timed populations with the one-step kernel only (``set_two_step(0)``); ``verified`` says
+whether the two final states are bit-identical; final mass and kinetic energy are in the line.
 cpu_baseline: the CPU oracle (a torch-CPU restatement of the reference's path, validated
 against the reference) timed on this box's host cores on the same 256^3 workload for a few
-steps (rank 0, N = 1 only).
+steps (rank 0, N = 1 only), at all host threads and at 32 threads; the better one is ``value``.
 """
 import argparse
 import json
@@ -44,14 +63,18 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3
 BYTES_PER_NODE = 2 * 19 * 4      # D3Q19 fp32: every population read once, written once
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batches", type=int, default=5,
+                    help="timed batches of --steps steps each; the median one is reported")
     ap.add_argument("--size", type=int, default=256, help="nodes per side of the per-GPU block")
-    ap.add_argument("--cpu-baseline-steps", type=int, default=3)
+    ap.add_argument("--cpu-baseline-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the untimed re-run with the one-step kernel (profiling passes)")
     ap.add_argument("--no-overlap", action="store_true", help="slab path: exchange without overlap")
     ap.add_argument("--transport", choices=["auto", "rccl", "window"], default="auto",
                     help="slab path: ghost-plane transport (lettuce_amd/_slab.py); auto = run the "
@@ -61,22 +84,62 @@ def parse():
     ap.add_argument("--slab", action="store_true",
                     help="use the z-slab driver (and an RCCL process group) even with one GPU: "
                          "rehearsal of the N > 1 code path")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ---- launching N ranks ------------------------------------------------------------------------
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, worker=None, visible=None, timeout=None):
+    """Run ``worker`` (default: this file) as n ranks of one node through ``torch.distributed.run``
+    in a CHILD process and return its exit code; the child's stdout (rank 0's JSON line) goes to
+    this process's stdout.  Must be called before anything in this process has initialised the
+    GPU: ``torch.cuda.device_count()`` does not.  ``visible`` overrides the device count (tests)."""
+    import subprocess
+    if visible is None:
+        visible = torch.cuda.device_count()
+    if visible < n:
+        sys.stderr.write(f"bench.py: --gpus {n} requested but only {visible} GPU(s) are visible on this "
+                         f"node; refusing to run a smaller job under the name of n_gpus = {n}\n")
+        return 3
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           worker or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    proc = subprocess.run(cmd, env=env, timeout=timeout)
+    if proc.returncode != 0:
+        sys.stderr.write(f"bench.py: the {n}-rank job exited with code {proc.returncode}\n")
+    return proc.returncode
 
 
 def cpu_baseline(size, steps):
-    """The oracle on the host cores, same workload, bounded sample."""
+    """The oracle on the host cores, same workload, bounded sample: at every host thread torch
+    uses by default and at 32 threads (the torch-CPU path stops scaling long before 128)."""
     from oracle import lettuce_oracle as orc
-    threads = torch.get_num_threads()
-    sim = orc.taylor_green([size] * 3, 1600, 0.1, "D3Q19", torch.float32)
-    sim.step(1)                                   # warm-up (allocator, thread pool)
-    t0 = time.perf_counter()
-    sim.step(steps)
-    dt = time.perf_counter() - t0
-    return {"value": round(steps * size ** 3 / 1e6 / dt, 3), "unit": "MLUPS", "cores": threads,
-            "kind": "port",
+    default = torch.get_num_threads()
+    runs = []
+    for threads in dict.fromkeys([default, min(default, 32)]):
+        torch.set_num_threads(threads)
+        sim = orc.taylor_green([size] * 3, 1600, 0.1, "D3Q19", torch.float32)
+        sim.step(1)                                   # warm-up (allocator, thread pool)
+        t0 = time.perf_counter()
+        sim.step(steps)
+        dt = time.perf_counter() - t0
+        runs.append((round(steps * size ** 3 / 1e6 / dt, 3), threads))
+        del sim
+    torch.set_num_threads(default)
+    best = max(runs)
+    return {"value": best[0], "unit": "MLUPS", "cores": best[1], "kind": "port",
             "sample": f"oracle/lettuce_oracle.py (torch CPU ops), TGV3D D3Q19 BGK fp32 {size}^3, "
-                      f"{steps} steps after 1 warm-up step, {threads} threads"}
+                      f"{steps} steps after 1 warm-up step per thread count; "
+                      + ", ".join(f"{v} MLUPS at {t} threads" for v, t in runs)
+                      + f"; host has {os.cpu_count()} logical CPUs"}
 
 
 def copy_ceiling(device, nbytes=1 << 30, iters=20):
@@ -98,16 +161,30 @@ def copy_ceiling(device, nbytes=1 << 30, iters=20):
     return best
 
 
+def source_hash():
+    """Hash of the kernel sources the in-tree library is built from (lettuce_amd/csrc)."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "lettuce_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hpp", ".hip", ".inc")):
+            with open(os.path.join(src, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def traffic_from_profile(kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/traffic.json, produced by tools/pmc_traffic.py on the GPU box); null if absent."""
+    (profiles/traffic.json, produced by tools/pmc_traffic.py on the GPU box) -- only if that file
+    was measured on a build of the same kernel sources (its ``source_hash``); else null."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
             table = json.load(fh)
+        if table.get("source_hash") != source_hash():
+            return None
         # the engine's name and rocprofv3's differ in case, in the "void lt::" prefix and in what
-        # follows the argument list; template parameters appended later (with defaults that keep the
-        # old behaviour) make one name a prefix of the other
+        # follows the argument list
         def core(name):
             name = name.lower().replace(" ", "")
             name = name[name.index("lbm"):] if "lbm" in name else name
@@ -143,16 +220,29 @@ def ensure_library(local_rank):
     time.sleep(2)          # let the linker finish writing
 
 
+def median_index(values):
+    order = sorted(range(len(values)), key=lambda i: values[i])
+    return order[len(order) // 2]
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: become one (nothing in this process has touched the GPU yet)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(or drop the launcher and let bench.py start the ranks itself)")
     ensure_library(local_rank)
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"local rank {local_rank} has no GPU: {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed = world > 1 or args.slab
@@ -179,6 +269,7 @@ def main():
         nodes_per_rank = n ** 3
         kernel = sim._native.plan.kernel_name()
         sim(args.warmup)
+        pre_timed = None if args.no_verify else flow.f.clone()   # lettuce's convention: post-streaming
         sim._native.fused_events = (start, end)
         step = sim
         parallelism = "single GPU"
@@ -274,6 +365,12 @@ def main():
                     continue
             eligible.append(name)
         chosen = min(eligible, key=lambda k: probe[k])
+        # what every rank ended the warm-up with, for the record: RCCL really saw `world` ranks, each
+        # with its own slab (sum of the populations of the chosen candidate, per rank)
+        mine = torch.tensor([float(finals[chosen].double().sum())], dtype=torch.float64, device=device)
+        sums = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(sums, mine)
+        rank_checksums = [round(float(x.item()), 6) for x in sums]
         finals.clear()
         reference = state = None
         torch.cuda.empty_cache()
@@ -289,67 +386,96 @@ def main():
         how += ("; two lattice updates per launch, one exchange per two updates" if driver == "two-step"
                 else "; one exchange per update")
         parallelism = f"z-slab x{world}, {how}" + ("" if not args.no_overlap else " (no overlap)")
-        transport_info = {"chosen": chosen, "warmup_ms_per_step": probe, "checks": checks}
+        transport_info = {"chosen": chosen, "warmup_ms_per_step": probe, "checks": checks,
+                          "ranks_seen": world, "rank_checksums_after_warmup": rank_checksums}
 
-    barrier()
-    t0 = time.perf_counter()
-    step(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if distributed:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    # ---- the timed region: `batches` times exactly K steps, each between barrier + synchronise ----
+    batch_s, batch_fused_ms, batch_info = [], [], []
+    for _ in range(max(1, args.batches)):
+        barrier()
+        t0 = time.perf_counter()
+        step(args.steps)
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        batch_s.append(float(t.item()))
+        if not distributed and args.steps > 1:
+            info = sim._native.plan.last_run_info()
+            batch_info.append(info)
+            batch_fused_ms.append(start.elapsed_time(end))
+    mid = median_index(batch_s)
+    elapsed = batch_s[mid]
     total_nodes = nodes_per_rank * world
     mlups = args.steps * total_nodes / 1e6 / elapsed
 
     roofline = None
+    check = None
     if not distributed and args.steps > 1:
         # what the events bracketed: the two-step launches (two lattice updates per node each) when
         # lt_run paired its fused steps, else the single-step launches
-        info = sim._native.plan.last_run_info()
+        info = batch_info[mid]
         paired = info["two_step_launches"] > 0
         launches = info["two_step_launches"] if paired else info["single_step_launches"]
-        updates_per_launch = (2 if paired else 1) * nodes_per_rank
-        fused_ms = start.elapsed_time(end) / launches
-        achieved = BYTES_PER_NODE * updates_per_launch / (fused_ms * 1e-3) / 1e9
+        updates_per_launch = 2 if paired else 1
+        fused_ms = batch_fused_ms[mid] / launches
+        hbm_bytes = BYTES_PER_NODE * nodes_per_rank            # one read + one write of every population
+        achieved = hbm_bytes / (fused_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic_from_profile(kernel),
                     "kernel": kernel, "avg_launch_ms": round(fused_ms, 5),
-                    "lattice_updates_per_launch": updates_per_launch,
-                    "algorithmic_bytes_per_launch": BYTES_PER_NODE * updates_per_launch,
-                    "launches_timed": launches}
+                    "hbm_bytes_per_launch_required": hbm_bytes,
+                    "lattice_updates_per_node_per_launch": updates_per_launch,
+                    "algorithmic_update_GBps": round(achieved * updates_per_launch, 1),
+                    "launches_timed": launches, "source_hash": source_hash()}
         if roofline["traffic"]:
             # what HBM really carried per second during the launch (PMC bytes / live duration)
             real = roofline["traffic"] / (fused_ms * 1e-3) / 1e9
             roofline["hbm_traffic_GBps"] = round(real, 1)
             roofline["hbm_traffic_frac_of_peak"] = round(real / HBM_PEAK_GBS, 4)
-        if paired:
-            roofline["note"] = ("two lattice updates per node per launch, the intermediate state staged "
-                                "in LDS: HBM traffic per launch (traffic) is below the algorithmic bytes "
-                                "of two updates, so achieved may exceed what HBM itself delivers")
+        roofline["note"] = ("achieved = populations read once + written once per launch / launch time (a physical "
+                            "HBM rate)" + ("; the launch performs two lattice updates per node with the intermediate "
+                                           "state in LDS, algorithmic_update_GBps counts 152 B per node and update"
+                                           if paired else ""))
         ceiling = copy_ceiling(device)
         roofline["copy_ceiling_GBps"] = round(ceiling, 1)
         roofline["frac_of_copy_ceiling"] = round(achieved / ceiling, 4)
+        # ---- self-check of the timed result (untimed) ------------------------------------------
+        mass = float(sim._native.plan.mass(flow.f))             # device reductions (lt_mass, lt_kinetic_energy)
+        energy = float(lt.IncompressibleKineticEnergy(flow)())
+        check = {"verified": None, "final_mass_lu": mass, "final_E_pu": energy,
+                 "steps_checked": len(batch_s) * args.steps}
+        if pre_timed is not None:
+            final = flow.f.clone()
+            flow2 = lt.TaylorGreenVortex(ctx, [n, n, n], 1600, 0.1, lt.D3Q19())
+            flow2.f = pre_timed
+            sim2 = lt.Simulation(flow2, lt.BGKCollision(flow2.units.relaxation_parameter_lu), [])
+            sim2._native.plan.set_two_step(0)                  # one lattice update per launch
+            sim2(len(batch_s) * args.steps)
+            info2 = sim2._native.plan.last_run_info()
+            check["verified"] = bool(torch.equal(flow2.f, final)) and info2["two_step_launches"] == 0
+            check["how"] = ("the same steps repeated from a copy of the pre-timed populations with the one-step "
+                            f"kernel ({sim2._native.plan.kernel_name()}), torch.equal on all populations")
+            del flow2, sim2, final, pre_timed
     elif distributed:
         # per-rank fused-kernel rate is not separable from the exchange here; report the
         # effective whole-step rate of one rank against the same algorithmic bytes
         eff = BYTES_PER_NODE * nodes_per_rank * args.steps / elapsed / 1e9
         roofline = {"bound": "hbm", "achieved": round(eff, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(eff / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
-                    "note": "whole-step effective rate per GPU (includes halo exchange and the "
-                            "collide/stream passes of the batch)"}
+                    "note": "whole-step effective rate per GPU in algorithmic bytes (152 B per node and update; "
+                            "includes halo exchange and the collide/stream passes of the batch); with the two-step "
+                            "driver HBM carries about half of it"}
 
     passes = "1 collide + (K-1) fused stream-collide + 1 stream"
-    if not distributed and args.steps > 1 and roofline.get("lattice_updates_per_launch", 0) > nodes_per_rank:
+    if roofline and roofline.get("lattice_updates_per_node_per_launch", 0) == 2:
         # the timed call continues from the post-collision state the warm-up call left (lt_continue)
         passes = ("K fused stream-collide steps as K/2 two-step launches (+1 single when K is odd) + 1 stream, "
-                  "continuing from the post-collision populations of the warm-up batch")
+                  "continuing from the post-collision populations of the previous batch")
     if rank == 0:
         line = {
-            "metric": "MLUPS (million lattice updates/s) D3Q19 256\u00b3 TGV; achieved HBM GB/s vs peak",
+            "metric": "MLUPS (million lattice updates/s) D3Q19 256³ TGV; achieved HBM GB/s vs peak",
             "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -359,8 +485,12 @@ def main():
                                    f"({nodes_per_rank} nodes per GPU), Re=1600 Ma=0.1",
                        "global_resolution": global_res, "parallelism": parallelism,
                        "passes_per_batch": passes},
+            "batches_ms_per_step": [round(t / args.steps * 1e3, 5) for t in batch_s],
+            "timing": f"median of {len(batch_s)} timed batches of {args.steps} steps",
             "roofline": roofline,
         }
+        if check is not None:
+            line.update(check)
         if distributed:
             line["config"]["transport"] = transport_info
         if not distributed and not args.no_cpu_baseline:

@@ -23,8 +23,8 @@
  *                        -- exactly the reference's C-contiguous tensor (lettuce/_flow.py:90).
  *   LT_LAYOUT_SLAB       3-D only, a0 = x, a2 = z: f[q][z][y][x]; used by the multi-GPU
  *                        z-slab driver so that ghost planes are contiguous.
- * ghost_planes = 1 adds one plane below and one above along a2 (slab exchange);
- * then a2 has shape_a2 + 2 planes and no periodic wrap is applied along it.
+ * ghost_planes = g (1, or 2 for the two-step slab driver) adds g planes below and g above along
+ * a2 (slab exchange); then a2 has shape_a2 + 2 g planes and no periodic wrap is applied along it.
  *
  * Error convention: every function returns LT_OK (0) or a positive LT_ERR_* code
  * and never aborts; lt_last_error() gives the message of the calling thread's
@@ -88,7 +88,7 @@ typedef struct lt_plan_desc {
   int32_t dtype;           /* lt_dtype */
   int32_t collision;       /* lt_collision */
   int32_t layout;          /* lt_layout */
-  int32_t ghost_planes;    /* 0, or 1 (LT_LAYOUT_SLAB only) */
+  int32_t ghost_planes;    /* 0; or 1 / 2 (LT_LAYOUT_SLAB only; 2 for the two-step slab entry points) */
   int32_t dims;            /* 1, 2 or 3; must match the stencil */
   int32_t n_boundaries;    /* 0 .. LT_MAX_BOUNDARIES */
   int64_t shape[3];        /* logical resolution (nx, ny, nz); unused trailing entries = 1.  With ghost
@@ -259,9 +259,10 @@ int lt_plan_set_graph_mode(lt_plan *plan, int32_t mode);
 int lt_plan_set_tuning(lt_plan *plan, int32_t cache_policy, int32_t wide);
 /* Two fused steps in one launch: out = (C S)^2 f for the whole periodic grid, the intermediate
  * state staged through LDS (one HBM read and one write of the populations per two lattice updates).
- * Bit-identical to two lt_stream_collide calls.  Exists for D3Q19 with BGK / no collision on grids
- * without masks whose contiguous extent is a multiple of 64 (fp32) / 32 (fp64) and whose middle
- * extent is a multiple of 8; LT_ERR_UNSUPPORTED otherwise. */
+ * Bit-identical to two lt_stream_collide calls.  Exists for the 3-D lattices with BGK / no collision
+ * (D3Q15 and D3Q19 in fp32 and fp64, D3Q27 in fp32) on grids whose contiguous extent is a multiple
+ * of 64 (fp32) / 32 (fp64) and whose middle extent is a multiple of 8 (D3Q27: of 4);
+ * LT_ERR_UNSUPPORTED otherwise. */
 int lt_stream_collide_twice(lt_plan *plan, const void *f_dev, void *out_dev, double tau, void *stream);
 /* Small 2-D grids (launch-bound): n_steps <= 8 stream-collide steps in one launch.  Every workgroup
  * keeps the neighbourhood of its 8 x 8 tile in LDS and recomputes the halo, so the launch does

@@ -13,6 +13,8 @@
 
 namespace {
 
+// per calling thread: a caller must read lt_last_error() on the thread whose call failed (the ctypes
+// binding does, right after the failing call, before anything can migrate the Python thread)
 thread_local char g_error[512] = "";
 
 int fail(int code, const char *fmt, ...) {

@@ -12,7 +12,7 @@ reference's own CPU path in the build container (``oracle/gen_golden.py``;
 the reference itself never travels).  The reference holds no stored golden
 vectors of its own, so its invariants (mass/momentum
 conservation, bounce-back = opposite permutation, analytic ABB formula) are
-additionally restated in ``tests/test_oracle_invariants.py``.
+additionally restated in ``tests/test_reference_invariants.py``.
 
 All citations are ``path:line`` under ``/root/reference/``.
 

@@ -56,7 +56,10 @@ def main(tag, nodes=256 ** 3, q=19, esize=4, workload="tgv3d_d3q19_bgk_f32_256")
                         "lattice_updates_per_node_per_launch": updates,
                         "algorithmic_bytes_per_launch": updates * 2 * alg,
                         "traffic_over_algorithmic": round((rd + wr) / (updates * 2 * alg), 4)})
-    json.dump({"tag": tag, "note": __doc__.split("gfx950 corrections")[1].strip(), "kernels": kernels},
+    sys.path.insert(0, ROOT)
+    from bench import source_hash           # bench.py uses the table only for a build of these sources
+    json.dump({"tag": tag, "source_hash": source_hash(),
+               "note": __doc__.split("gfx950 corrections")[1].strip(), "kernels": kernels},
               open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     for k in kernels:
         print(k["kernel"][:70], k["hbm_bytes_per_launch"], k["traffic_over_algorithmic"])
