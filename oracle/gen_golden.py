@@ -44,7 +44,21 @@ def ke(flow):
     return float(lt.IncompressibleKineticEnergy(flow)())
 
 
+def enstrophy(flow):
+    """the reference's Enstrophy observable (periodic flows only; observable_reporter.py:45-68)"""
+    return float(lt.Enstrophy(flow)())
+
+
+ONLY = sys.argv[1:]          # optional: substrings of the case names to (re)generate
+
+
+def wanted(name):
+    return not ONLY or any(k in name for k in ONLY)
+
+
 def save(name, **arrays):
+    if not wanted(name):
+        return
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrays)
@@ -59,11 +73,14 @@ DT = {"f64": torch.float64, "f32": torch.float32}
 
 
 # --------------------------------------------------------------------------- #
-def run_series(flow, collision, snapshots, energy_every):
-    """Step to max(snapshots); record f at the snapshot steps and KE series."""
+def run_series(flow, collision, snapshots, energy_every, periodic=False):
+    """Step to max(snapshots); record f at the snapshot steps and KE series (periodic flows: also
+    the enstrophy and the Mass observable of the reference at the same steps)."""
     sim = quiet(lt.Simulation, flow, collision, [])
     out = {"f0": npy(flow.f)}
     steps, energies = [0], [ke(flow)]
+    ens = [enstrophy(flow)] if periodic else None
+    mass = [float(lt.Mass(flow)(flow.f))] if periodic else None
     last = max(snapshots)
     for i in range(1, last + 1):
         quiet(sim, 1)
@@ -72,8 +89,14 @@ def run_series(flow, collision, snapshots, energy_every):
         if i % energy_every == 0:
             steps.append(i)
             energies.append(ke(flow))
+            if periodic:
+                ens.append(enstrophy(flow))
+                mass.append(float(lt.Mass(flow)(flow.f)))
     out["energy_steps"] = np.array(steps)
     out["energy_pu"] = np.array(energies, dtype=np.float64)
+    if periodic:
+        out["enstrophy_pu"] = np.array(ens, dtype=np.float64)
+        out["mass_observable"] = np.array(mass, dtype=np.float64)
     out["rho_final"] = npy(flow.rho())
     out["u_final"] = npy(flow.u())
     if sim.no_collision_mask is not None:
@@ -84,16 +107,20 @@ def run_series(flow, collision, snapshots, energy_every):
 
 
 def tgv_case(name, res, stencil, re, ma, dt, coll, snapshots, energy_every):
+    if not wanted(name):
+        return
     ctx = lt.Context(device="cpu", dtype=DT[dt], use_native=False)
     flow = quiet(lt.TaylorGreenVortex, ctx, res, re, ma, stencil)
     tau = flow.units.relaxation_parameter_lu
     collision = lt.BGKCollision(tau) if coll == "bgk" else lt.KBCCollision()
-    out = run_series(flow, collision, snapshots, energy_every)
+    out = run_series(flow, collision, snapshots, energy_every, periodic=True)
     save(name, tau=np.float64(tau), reynolds=np.float64(re), mach=np.float64(ma),
          resolution=np.array(flow.resolution), **out)
 
 
 def obstacle_case(name, res, stencil, dt, coll, snapshots, domain_length_x, center, radius):
+    if not wanted(name):
+        return
     ctx = lt.Context(device="cpu", dtype=DT[dt], use_native=False)
     flow = quiet(lt.Obstacle, ctx, list(res), 100, 0.1, domain_length_x, stencil=stencil)
     grid = flow.grid
@@ -299,7 +326,7 @@ def shear3d_case(dt):
             lt.Flow.initialize(self)
     fl = quiet(Shear3D, ctx, n, lt.D3Q19(), 1000, 0.1)
     tau = fl.units.relaxation_parameter_lu
-    out = run_series(fl, lt.BGKCollision(tau), {5, 20}, 5)
+    out = run_series(fl, lt.BGKCollision(tau), {5, 20}, 5, periodic=True)
     save(f"shear3d_d3q19_bgk_{dt}", tau=np.float64(tau), **out)
 
 
@@ -316,6 +343,14 @@ if __name__ == "__main__":
     tgv_case("tgv3d_d3q27_bgk_16_f64", 16, lt.D3Q27(), 1600, 0.1, "f64", "bgk", {10}, 10)
     tgv_case("tgv3d_d3q27_kbc_16_f64", 16, lt.D3Q27(), 1600, 0.1, "f64", "kbc", {10, 50}, 10)
     tgv_case("tgv3d_d3q27_kbc_16_f32", 16, lt.D3Q27(), 1600, 0.1, "f32", "kbc", {10}, 10)
+    # grids the kernels with two lattice updates per launch take (last extent % 64 in fp32 / % 32 in fp64,
+    # middle extent % 8, D3Q27: % 4): direct vectors for lbm2_kernel and the two-step slab driver
+    tgv_case("tgv3d_d3q19_bgk_8x16x64_f32", [8, 16, 64], lt.D3Q19(), 400, 0.1, "f32", "bgk", {1, 2, 3, 10}, 5)
+    tgv_case("tgv3d_d3q19_bgk_8x8x32_f64", [8, 8, 32], lt.D3Q19(), 400, 0.1, "f64", "bgk", {1, 2, 3, 10}, 5)
+    tgv_case("tgv3d_d3q27_bgk_4x8x64_f32", [4, 8, 64], lt.D3Q27(), 400, 0.1, "f32", "bgk", {2, 3, 10}, 5)
+    tgv_case("tgv3d_d3q15_bgk_8x8x64_f32", [8, 8, 64], lt.D3Q15(), 400, 0.1, "f32", "bgk", {2, 3, 10}, 5)
+    # the slab layout has x contiguous: a grid the two-step slab driver takes (x % 64, y % 8)
+    tgv_case("tgv3d_d3q19_bgk_64x8x12_f32", [64, 8, 12], lt.D3Q19(), 400, 0.1, "f32", "bgk", {2, 9, 10}, 5)
     # anchors of SURVEY.md 8(c): TGV3D D3Q19 32^3, energies only + f after 10 steps (fp32)
     tgv_case("tgv3d_d3q19_bgk_32_f32", 32, lt.D3Q19(), 1600, 0.1, "f32", "bgk", {10}, 10)
     obstacle_case("obstacle2d_d2q9_bgk_f64", [32, 20], lt.D2Q9(), "f64", "bgk", {1, 2, 10},
@@ -326,7 +361,17 @@ if __name__ == "__main__":
                   4.0, (1.0, 1.2, 1.2), 0.5)
     obstacle_case("obstacle3d_d3q19_bgk_f64", [16, 12, 8], lt.D3Q19(), "f64", "bgk", {2, 8},
                   4.0, (1.0, 1.5, 1.0), 0.5)
-    hand_set_cases()
-    operator_cases()
-    shear3d_case("f64")
-    shear3d_case("f32")
+    # obstacle flows on tile-compatible grids (two-step kernel with masks)
+    obstacle_case("obstacle3d_d3q19_bgk_12x16x64_f32", [12, 16, 64], lt.D3Q19(), "f32", "bgk", {1, 2, 3, 8},
+                  4.0, (1.3, 2.0, 9.0), 0.8)
+    obstacle_case("obstacle3d_d3q27_bgk_10x8x64_f32", [10, 8, 64], lt.D3Q27(), "f32", "bgk", {1, 2, 3, 8},
+                  4.0, (1.3, 1.6, 12.0), 0.7)
+    obstacle_case("obstacle3d_d3q19_bgk_10x8x32_f64", [10, 8, 32], lt.D3Q19(), "f64", "bgk", {1, 2, 3, 8},
+                  4.0, (1.3, 1.6, 6.0), 0.7)
+    if wanted("native") or wanted("hand"):
+        hand_set_cases()
+    if wanted("operators"):
+        operator_cases()
+    if wanted("shear3d"):
+        shear3d_case("f64")
+        shear3d_case("f32")

@@ -455,6 +455,26 @@ def test_cfg1_populations_bit_identical_after_100_steps():
 
 
 # --------------------------------------------------------------------------- two steps per launch
+TWO_STEP_GOLDEN = [("tgv3d_d3q19_bgk_8x16x64_f32", "D3Q19", "f32", (1, 2, 3, 10)),
+                   ("tgv3d_d3q19_bgk_8x8x32_f64", "D3Q19", "f64", (1, 2, 3, 10)),
+                   ("tgv3d_d3q27_bgk_4x8x64_f32", "D3Q27", "f32", (2, 3, 10)),
+                   ("tgv3d_d3q15_bgk_8x8x64_f32", "D3Q15", "f32", (2, 3, 10))]
+
+
+@pytest.mark.parametrize("name,lat,dt,snaps", TWO_STEP_GOLDEN, ids=[t[0] for t in TWO_STEP_GOLDEN])
+def test_two_step_kernel_reproduces_the_reference_vectors_bit_for_bit(name, lat, dt, snaps):
+    """Direct vectors for lbm2_kernel: the reference's own CPU path stepped on grids the two-step kernel
+    takes; lt_run with the pairing forced on must return the reference's populations exactly, and must
+    really have gone through two-step launches (n steps = 1 collide + (n-1) fused + 1 stream)."""
+    g = golden(name)
+    plan = plan_for(lat, TORCH_DT[dt], "bgk", g["f0"].shape[1:])
+    plan.set_two_step(1)
+    for n in snaps:
+        np.testing.assert_array_equal(run_engine(plan, g["f0"], float(g["tau"]), n), g[f"f{n}"])
+        info = plan.last_run_info()
+        assert info["two_step_launches"] == (n - 1) // 2 and info["single_step_launches"] == (n - 1) % 2, info
+
+
 @pytest.mark.parametrize("res,seg", [([4, 8, 64], 0), ([8, 16, 64], 4), ([6, 24, 128], 3), ([1, 8, 64], 1),
                                      ([12, 40, 192], 0), ([5, 8, 64], 5)])
 @pytest.mark.parametrize("coll", ["none", "bgk"])

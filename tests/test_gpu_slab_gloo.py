@@ -100,6 +100,42 @@ def test_two_step_slab_is_bit_identical_to_the_single_step_slab(tmp_path, transp
     assert bool(np.load(tmp_path / "out.npz")["same"])
 
 
+def _golden_slab_worker(rank, port, res, steps, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    import lettuce_amd as lt
+    ctx = lt.Context("cuda:0", torch.float32, use_native=True)
+    from conftest import golden
+    f0 = torch.as_tensor(golden("tgv3d_d3q19_bgk_64x8x12_f32")["f0"]).cuda()
+    out = {}
+    for n in steps:
+        slab = lt.ZSlab(res)
+        flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 400, 0.1, lt.D3Q19(), slab=slab)
+        out.setdefault("f0_device", flow.f[..., slab.halo:-slab.halo].cpu().numpy())
+        # start from the reference's own initial populations (periodic extension by the slab's halo planes)
+        flow.f = torch.cat([f0[..., -slab.halo:], f0, f0[..., :slab.halo]], dim=-1).contiguous()
+        sim = lt.TwoStepSlabSimulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab)
+        sim(n)
+        out[f"f{n}"] = sim.gather_f().cpu().numpy()
+    np.savez(os.path.join(out_dir, "out.npz"), **out)
+    dist.destroy_process_group()
+
+
+def test_two_step_slab_driver_reproduces_the_reference_vectors_on_one_rank(tmp_path):
+    """TwoStepSlabSimulation (slab layout, two ghost planes, lt_stream_collide_twice_planes + halo messages to
+    itself) against vectors of the reference's CPU path on a grid its tiles take: bit-identical."""
+    from conftest import golden
+    g = golden("tgv3d_d3q19_bgk_64x8x12_f32")
+    mp.spawn(_golden_slab_worker, args=(29850 + os.getpid() % 1000, [64, 8, 12], (2, 9, 10), str(tmp_path)),
+             nprocs=1, join=True)
+    got = np.load(tmp_path / "out.npz")
+    np.testing.assert_allclose(got["f0_device"], g["f0"], rtol=0, atol=1e-6)     # device-side initial condition
+    for n in (2, 9, 10):
+        np.testing.assert_array_equal(got[f"f{n}"], g[f"f{n}"])
+
+
 def _rccl_worker(rank, port, res, steps, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -26,6 +26,12 @@ TGV = [
     ("tgv3d_d3q27_bgk_16_f64", "D3Q27", "bgk", "f64", (10,)),
     ("tgv3d_d3q27_kbc_16_f64", "D3Q27", "kbc", "f64", (10, 50)),
     ("tgv3d_d3q27_kbc_16_f32", "D3Q27", "kbc", "f32", (10,)),
+    # grids the kernels with two lattice updates per launch take
+    ("tgv3d_d3q19_bgk_8x16x64_f32", "D3Q19", "bgk", "f32", (1, 2, 3, 10)),
+    ("tgv3d_d3q19_bgk_8x8x32_f64", "D3Q19", "bgk", "f64", (1, 2, 3, 10)),
+    ("tgv3d_d3q27_bgk_4x8x64_f32", "D3Q27", "bgk", "f32", (2, 3, 10)),
+    ("tgv3d_d3q15_bgk_8x8x64_f32", "D3Q15", "bgk", "f32", (2, 3, 10)),
+    ("tgv3d_d3q19_bgk_64x8x12_f32", "D3Q19", "bgk", "f32", (2, 9, 10)),
 ]
 
 
