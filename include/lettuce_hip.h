@@ -231,6 +231,23 @@ int lt_mass(lt_plan *plan, const void *f_dev, double *out_dev, void *stream);
  * lettuce/ext/_reporter/observable_reporter.py:27-31; the pu scaling stays on the host). */
 int lt_max_velocity(lt_plan *plan, const void *f_dev, double *out_dev, void *stream);
 
+/* Enstrophy observable (lettuce/ext/_reporter/observable_reporter.py:45-68): *out_dev = sum over nodes
+ * of |curl(u_scale * u)|^2 with the 6th-order periodic central differences of torch_gradient
+ * (lettuce/util/utility.py:37-99; weights -1/60, 3/20, -3/4, 3/4, -3/20, 1/60 times inv_dx), evaluated
+ * per node in the working dtype as the reference's whole-field expression and accumulated in fp64
+ * with a fixed reduction order; the factor dx^d stays on the host.  Two launches: u [d][N] into
+ * u_scratch_dev (d * N scalars of the plan's dtype, caller-owned), then the stencil reduction over
+ * it.  2-D / 3-D, reference layout, periodic domains only (as the reference). */
+int lt_enstrophy(lt_plan *plan, const void *f_dev, void *u_scratch_dev, double u_scale, double inv_dx,
+                 double *out_dev, void *stream);
+
+/* Mass observable (observable_reporter.py:140-158): *out_dev = sum over all populations of the nodes
+ * that are not on the first / last index of the two fastest axes (the reference's f[..., 1:-1, 1:-1])
+ * minus, if no_mass_mask_dev (uint8 [N], 0 / 1) is given, sum_q f over the nodes it flags (borders
+ * included, as in the reference).  fp64 accumulation.  2-D / 3-D, reference layout. */
+int lt_mass_interior(lt_plan *plan, const void *f_dev, const uint8_t *no_mass_mask_dev, double *out_dev,
+                     void *stream);
+
 /* Introspection for tests and benchmarks. */
 int lt_plan_kernel_info(lt_plan *plan, int32_t *vec_width, int32_t *threads_per_block,
                         int64_t *blocks_per_launch);

@@ -82,6 +82,8 @@ SYMBOLS = {
     "lt_kinetic_energy": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "lt_mass": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "lt_max_velocity": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "lt_enstrophy": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _dbl, _vp, _vp]),
+    "lt_mass_interior": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "lt_plan_kernel_info": (ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i32),
                                            ctypes.POINTER(_i64)]),
     "lt_plan_kernel_name": (ctypes.c_char_p, [_vp]),
@@ -417,6 +419,32 @@ class Plan:
         self._tensor_ok(f, self.f_shape)
         out = torch.empty((), dtype=torch.float64, device=f.device)
         self._check(self.lib.lt_max_velocity(self._handle, _ptr(f), _ptr(out), _stream_handle()))
+        return out
+
+    @_on_device
+    def enstrophy_sum(self, f, u_scale: float, inv_dx: float):
+        """0-d float64 device tensor: sum over nodes of |curl(u_scale * u)|^2 (6th-order periodic
+        differences times inv_dx); one [d, *res] scratch field for u, nothing else is materialised."""
+        self._tensor_ok(f, self.f_shape)
+        scratch = torch.empty([self.d] + self.f_shape[1:], dtype=self.dtype, device=f.device)
+        out = torch.empty((), dtype=torch.float64, device=f.device)
+        self._check(self.lib.lt_enstrophy(self._handle, _ptr(f), _ptr(scratch), float(u_scale), float(inv_dx),
+                                          _ptr(out), _stream_handle()))
+        scratch.record_stream(torch.cuda.current_stream())
+        return out
+
+    @_on_device
+    def mass_interior(self, f, no_mass_mask: Optional[torch.Tensor] = None):
+        """0-d float64 device tensor: the reference's Mass observable (borders of the two fastest axes
+        excluded, the nodes of ``no_mass_mask`` subtracted)."""
+        self._tensor_ok(f, self.f_shape)
+        mask = None
+        if no_mass_mask is not None:
+            mask = torch.broadcast_to(no_mass_mask, self.f_shape[1:]).to(device=f.device, dtype=torch.uint8).contiguous()
+        out = torch.empty((), dtype=torch.float64, device=f.device)
+        self._check(self.lib.lt_mass_interior(self._handle, _ptr(f), _ptr(mask), _ptr(out), _stream_handle()))
+        if mask is not None:
+            mask.record_stream(torch.cuda.current_stream())
         return out
 
     # ------------------------------------------------------------------ introspection

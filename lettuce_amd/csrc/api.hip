@@ -520,7 +520,8 @@ int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, 
   return LT_OK;
 }
 
-int aux(lt_plan *p, int what, const void *f, void *rho, void *u, double *out, void *stream) {
+int aux(lt_plan *p, int what, const void *f, void *rho, void *u, double *out, void *stream,
+        double scale = 1.0, double inv_dx = 1.0, const unsigned char *mask = nullptr) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (!f) return fail(LT_ERR_INVALID, "null population buffer");
   lt::AuxArgs a;
@@ -532,6 +533,8 @@ int aux(lt_plan *p, int what, const void *f, void *rho, void *u, double *out, vo
   a.first = plane * p->interior_begin;
   a.count = plane * (p->interior_end - p->interior_begin);
   a.partial = p->partial; a.reduce_blocks = kReduceBlocks; a.out = out;
+  a.n0 = p->n0; a.n1 = p->n1; a.n2 = p->n2;
+  a.scale = scale; a.inv_dx = inv_dx; a.mask = mask;
   a.stream = static_cast<hipStream_t>(stream);
   const int r = p->unit.aux(a);
   if (r == lt::kNoKernel) return fail(LT_ERR_UNSUPPORTED, "no auxiliary kernel %d", what);
@@ -722,6 +725,19 @@ int lt_mass(lt_plan *p, const void *f, double *out, void *s) {
 int lt_max_velocity(lt_plan *p, const void *f, double *out, void *s) {
   if (!out) return fail(LT_ERR_INVALID, "null output");
   return aux(p, 4, f, nullptr, nullptr, out, s);
+}
+
+int lt_enstrophy(lt_plan *p, const void *f, void *u_scratch, double u_scale, double inv_dx, double *out, void *s) {
+  if (!out || !u_scratch) return fail(LT_ERR_INVALID, "null output / scratch");
+  if (p && (p->unit.d < 2 || p->desc.layout != LT_LAYOUT_REFERENCE || p->desc.ghost_planes))
+    return fail(LT_ERR_UNSUPPORTED, "enstrophy: 2-D / 3-D periodic grids in the reference layout");
+  return aux(p, 5, f, nullptr, u_scratch, out, s, u_scale, inv_dx);
+}
+int lt_mass_interior(lt_plan *p, const void *f, const uint8_t *mask, double *out, void *s) {
+  if (!out) return fail(LT_ERR_INVALID, "null output");
+  if (p && (p->unit.d < 2 || p->desc.layout != LT_LAYOUT_REFERENCE || p->desc.ghost_planes))
+    return fail(LT_ERR_UNSUPPORTED, "interior mass: 2-D / 3-D grids in the reference layout");
+  return aux(p, 6, f, nullptr, nullptr, out, s, 1.0, 1.0, mask);
 }
 
 int lt_plan_kernel_info(lt_plan *p, int32_t *vec, int32_t *tpb, int64_t *blocks) {

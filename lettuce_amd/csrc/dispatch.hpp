@@ -30,7 +30,7 @@ struct StepArgs {
 };
 
 struct AuxArgs {
-  int what;              // 0 macroscopic, 1 equilibrium, 2 kinetic energy, 3 mass, 4 max |u|
+  int what;              // 0 macroscopic, 1 equilibrium, 2 kinetic energy, 3 mass, 4 max |u|, 5 enstrophy, 6 interior mass
   int layout;
   const void *f;         // populations (what 0, 2, 3) / feq output (what 1; cast away const)
   void *rho;             // what 0: out, what 1: in
@@ -40,6 +40,9 @@ struct AuxArgs {
   double *partial;       // plan scratch, >= reduce_blocks doubles
   int reduce_blocks;
   double *out;           // device scalar
+  int n0, n1, n2;        // memory extents (what 5, 6)
+  double scale, inv_dx;  // what 5: u_pu = scale * u_lu, 1 / dx_pu
+  const unsigned char *mask;   // what 6: no-mass mask or null
   hipStream_t stream;
 };
 

@@ -1160,6 +1160,71 @@ __global__ void __launch_bounds__(kThreads) reduce_kernel(const T *__restrict__ 
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+// Enstrophy (observable_reporter.py:45-68) from the velocity field u [d][N] (lattice units, logical
+// component order, reference layout): per node the 6th-order periodic central differences of
+// torch_gradient (util/utility.py:37-99) of u_pu = scale * u, the squared vorticity, fp64 partial sums.
+// d(u_c)/d(axis): sum_k w_k u_c(x - s_k e_axis), s = 3, 2, 1, -1, -2, -3, times 1 / dx -- the order of
+// the reference's expression (roll by +s reads x - s).
+template <typename T, int D>
+__global__ void __launch_bounds__(kThreads) enstrophy_kernel(const T *__restrict__ u, int n0, int n1, int n2,
+                                                            T scale, T inv_dx, double *__restrict__ partial) {
+#pragma clang fp contract(off)
+  const long long N = (long long)n0 * n1 * n2;
+  const T w[6] = {T(-1. / 60.), T(3. / 20.), T(-3. / 4.), T(3. / 4.), T(-3. / 20.), T(1. / 60.)};
+  const int sh[6] = {3, 2, 1, -1, -2, -3};
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < N; i += (long long)gridDim.x * kThreads) {
+    const int c0 = (int)(i % n0), c1 = (int)((i / n0) % n1), c2 = (int)(i / ((long long)n0 * n1));
+    // derivative of component c along MEMORY axis m
+    auto ddx = [&](int c, int m) -> T {
+      const T *uc = u + (long long)c * N;
+      T r = T(0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        int a0 = c0, a1 = c1, a2 = c2;
+        if (m == 0) { a0 = c0 - sh[k]; a0 = a0 < 0 ? a0 + n0 : (a0 >= n0 ? a0 - n0 : a0); }
+        if (m == 1) { a1 = c1 - sh[k]; a1 = a1 < 0 ? a1 + n1 : (a1 >= n1 ? a1 - n1 : a1); }
+        if (m == 2) { a2 = c2 - sh[k]; a2 = a2 < 0 ? a2 + n2 : (a2 >= n2 ? a2 - n2 : a2); }
+        const T v = w[k] * (uc[((long long)a2 * n1 + a1) * n0 + a0] * scale);
+        r = k == 0 ? v : r + v;
+      }
+      return r * inv_dx;
+    };
+    // logical axis a lives on memory axis D - 1 - a (reference layout)
+    auto grad = [&](int c, int a) -> T { return ddx(c, D - 1 - a); };
+    const T wz = grad(0, 1) - grad(1, 0);
+    T node = wz * wz;
+    if constexpr (D == 3) {
+      const T wx = grad(2, 1) - grad(1, 2), wy = grad(0, 2) - grad(2, 0);
+      node = node + (wx * wx + wy * wy);
+    }
+    acc += (double)node;
+  }
+  const double s = block_sum<false>(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// Mass observable (observable_reporter.py:140-158): sum of all populations over the nodes off the first /
+// last index of the two fastest axes, minus the populations of the nodes flagged by `mask` (anywhere)
+template <typename T, int Q>
+__global__ void __launch_bounds__(kThreads) interior_mass_kernel(const T *__restrict__ f, long long N, int n0, int n1,
+                                                                const unsigned char *__restrict__ mask,
+                                                                double *__restrict__ partial) {
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < N; i += (long long)gridDim.x * kThreads) {
+    const int c0 = (int)(i % n0), c1 = (int)((i / n0) % n1);
+    const bool inner = c0 > 0 && c0 < n0 - 1 && c1 > 0 && c1 < n1 - 1;
+    const bool masked = mask != nullptr && mask[i] != 0;
+    if (!inner && !masked) continue;
+    double node = 0.0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) node += (double)f[(long long)q * N + i];
+    acc += (inner ? node : 0.0) - (masked ? node : 0.0);
+  }
+  const double s = block_sum<false>(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
 template <bool MAX>
 static __global__ void __launch_bounds__(kThreads) finish_sum_kernel(const double *__restrict__ partial,
                                                               int n, double *__restrict__ out) {

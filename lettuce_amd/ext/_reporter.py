@@ -1,8 +1,9 @@
 """Observables read between steps ("next" row F3) and the reporter that logs them.
 
 API of lettuce/ext/_reporter/observable_reporter.py:17-42,140-199.  On a native context the
-kinetic energy and the mass are device-side wavefront/LDS reductions in fp64
-(``lt_kinetic_energy`` / ``lt_mass``) -- no [d, *res] velocity field is materialised.
+kinetic energy, the maximum velocity, the enstrophy and the Mass observable are device-side
+wavefront/LDS reductions in fp64 (``lt_kinetic_energy``, ``lt_max_velocity``, ``lt_enstrophy``,
+``lt_mass_interior``); the enstrophy uses one [d, *res] scratch field for u, the others none.
 VTK / HDF5 / image writers, the energy spectrum and the error reporter are host-side
 post-processing and out of scope.
 """
@@ -64,6 +65,11 @@ class Enstrophy(Observable):
     def __call__(self, f: Optional[torch.Tensor] = None):
         flow = self.flow
         dx = flow.units.convert_length_to_pu(1.0)
+        plan = flow._engine_plan(flow.f) if flow.stencil.d >= 2 else None
+        if plan is not None:
+            # device reduction (lt_enstrophy): u into one scratch field, then the vorticity stencil
+            total = plan.enstrophy_sum(flow.f, flow.units.convert_velocity_to_pu(1.0), 1.0 / dx)
+            return (total * dx ** flow.stencil.d).to(flow.f.dtype)
         u = flow.units.convert_velocity_to_pu(flow.u())
         grad = [torch_gradient(u[a], dx=dx, order=6) for a in range(flow.stencil.d)]
         w_z = grad[0][1] - grad[1][0]
@@ -83,6 +89,9 @@ class Mass(Observable):
         self.mask = no_mass_mask
 
     def __call__(self, f: Optional[torch.Tensor] = None):
+        plan = self.flow._engine_plan(f) if (f is not None and self.flow.stencil.d >= 2) else None
+        if plan is not None and (self.mask is None or list(self.mask.shape) == list(f.shape[1:])):
+            return plan.mass_interior(f, self.mask).to(f.dtype)      # device reduction (lt_mass_interior)
         mass = f[..., 1:-1, 1:-1].sum()
         if self.mask is not None:
             mass -= (f * self.mask.to(dtype=torch.float)).sum()

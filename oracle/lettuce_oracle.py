@@ -469,6 +469,30 @@ def periodic_gradient6(g):
     return torch.stack(out)
 
 
+def enstrophy_pu(f, lat: Lattice, units: Units):
+    """Enstrophy observable (lettuce/ext/_reporter/observable_reporter.py:45-68): squared vorticity of
+    u_pu from 6th-order periodic differences (util/utility.py:37-99), summed, times dx^d."""
+    e, _ = lattice_tensors(lat, f.dtype)
+    u = velocity(f, e) * (units.characteristic_velocity_pu / units.u_char_lu)
+    dx = units.length_to_pu(1.0)
+    inv = torch.tensor(1.0 / dx, dtype=f.dtype)
+    g = [periodic_gradient6(u[a]) * inv for a in range(lat.d)]
+    vort = torch.sum((g[0][1] - g[1][0]) * (g[0][1] - g[1][0]))
+    if lat.d == 3:
+        vort = vort + torch.sum((g[2][1] - g[1][2]) * (g[2][1] - g[1][2])
+                                + ((g[0][2] - g[2][0]) * (g[0][2] - g[2][0])))
+    return vort * dx ** lat.d
+
+
+def mass_observable(f, no_mass_mask=None):
+    """Mass observable (observable_reporter.py:140-158): the first / last index of the two last axes
+    does not count; the nodes of ``no_mass_mask`` are subtracted (wherever they are)."""
+    mass = f[..., 1:-1, 1:-1].sum()
+    if no_mass_mask is not None:
+        mass = mass - (f * no_mass_mask.to(dtype=torch.float)).sum()
+    return mass
+
+
 def tgv_units(resolution, reynolds_number, mach_number):
     return Units(reynolds_number, mach_number,
                  characteristic_length_lu=resolution[0],

@@ -170,6 +170,12 @@ def test_taylor_green_with_reporter_batches(name, stencil, coll, dt, n):
         assert e == pytest.approx(ref[i], rel=rel)
     atol = (1e-12 if dt == "f64" else 1e-5) * float(np.abs(g[f"f{n}"]).max())
     np.testing.assert_allclose(flow.f.cpu().numpy(), g[f"f{n}"], rtol=0, atol=atol)
+    # the Enstrophy and Mass observables on the same state, as device reductions (row F3)
+    at = g["energy_steps"].tolist().index(n)
+    ens, mass = lt.Enstrophy(flow)(), lt.Mass(flow)(flow.f)
+    assert ens.is_cuda and ens.dtype == flow.f.dtype and mass.is_cuda
+    assert float(ens) == pytest.approx(float(g["enstrophy_pu"][at]), rel=1e-9 if dt == "f64" else 2e-5)
+    assert float(mass) == pytest.approx(float(g["mass_observable"][at]), rel=1e-12 if dt == "f64" else 1e-5)
 
 
 @pytest.mark.parametrize("name,stencil,coll,dt", [("obstacle2d_d2q9_bgk_f64", lt.D2Q9, "bgk", "f64"),

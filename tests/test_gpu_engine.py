@@ -250,6 +250,43 @@ def test_fused_equals_collide_then_stream_and_ab_variants_agree():
             torch.testing.assert_close(c, b, rtol=0, atol=tol)
 
 
+OBSERVED = [("tgv2d_d2q9_bgk_32_f64", "D2Q9", "f64", (0, 10, 100)), ("tgv2d_d2q9_bgk_32_f32", "D2Q9", "f32", (0, 10)),
+            ("tgv3d_d3q19_bgk_16_f64", "D3Q19", "f64", (0, 10, 100)), ("tgv3d_d3q19_bgk_16_f32", "D3Q19", "f32", (0, 10)),
+            ("tgv3d_d3q19_bgk_ragged_f64", "D3Q19", "f64", (0, 7)), ("tgv3d_d3q27_kbc_16_f64", "D3Q27", "f64", (0, 10, 50)),
+            ("tgv3d_d3q19_bgk_8x16x64_f32", "D3Q19", "f32", (0, 10)), ("shear3d_d3q19_bgk_f64", "D3Q19", "f64", (0, 5, 20))]
+
+
+@pytest.mark.parametrize("name,lat,dt,snaps", OBSERVED, ids=[t[0] for t in OBSERVED])
+def test_enstrophy_and_mass_device_reductions_match_the_reference(name, lat, dt, snaps):
+    """lt_enstrophy (u pass + 6th-order vorticity stencil, fp64 reduction) and lt_mass_interior against the
+    values of the reference's Enstrophy / Mass observables on the same populations (row F3)."""
+    g = golden(name)
+    steps = g["energy_steps"].tolist()
+    res = g["f0"].shape[1:]
+    plan = plan_for(lat, TORCH_DT[dt], "none", res)
+    if name.startswith("tgv"):
+        units = orc.tgv_units([int(r) for r in g["resolution"]], float(g["reynolds"]), float(g["mach"]))
+        u_scale, dx = units.characteristic_velocity_pu / units.u_char_lu, units.length_to_pu(1.0)
+    else:
+        u_scale = dx = None
+    for i in snaps:
+        f = dev(g[f"f{i}"])
+        at = steps.index(i)
+        mass = float(plan.mass_interior(f))
+        # fp32: the reference sums 1e5 .. 1e6 terms in fp32 (torch.sum), the kernel in fp64
+        assert mass == pytest.approx(float(g["mass_observable"][at]), rel=1e-13 if dt == "f64" else 1e-5)
+        if u_scale is not None:
+            ens = float(plan.enstrophy_sum(f, u_scale, 1.0 / dx)) * dx ** len(res)
+            assert ens == pytest.approx(float(g["enstrophy_pu"][at]), rel=1e-9 if dt == "f64" else 1e-5)
+    # a no-mass mask: flagged nodes are subtracted wherever they are (borders included)
+    torch.manual_seed(5)
+    mask = (torch.rand(list(res)) < 0.2)
+    f = torch.as_tensor(g["f0"])
+    want = float(orc.mass_observable(f.double(), mask))
+    got = float(plan.mass_interior(dev(g["f0"]), mask.cuda()))
+    assert got == pytest.approx(want, rel=1e-12 if dt == "f64" else 1e-5)
+
+
 def test_energy_decay_series_fp64():
     """TGV kinetic-energy decay vs the reference's series (north-star parity metric, 1e-6 rel)."""
     g = golden("tgv3d_d3q19_bgk_16_f64")

@@ -325,16 +325,24 @@ def test_three_instruction_division_by_the_cs2_constants_is_the_ieee_quotient(tm
         assert out.returncode == 0 and out.stdout.strip() == "mismatches 0", (args, out.stdout, out.stderr)
 
 
-def test_bench_finds_the_committed_pmc_traffic_for_the_fused_kernel():
-    """bench.py fills roofline.traffic from profiles/traffic.json by kernel name; the name the
-    engine reports (lt_plan_kernel_name) and the one rocprofv3 prints differ in case and suffix."""
+def test_bench_finds_the_committed_pmc_traffic_for_the_fused_kernel(monkeypatch):
+    """bench.py fills roofline.traffic from profiles/traffic.json by kernel name -- the name the engine
+    reports (lt_plan_kernel_name) and the one rocprofv3 prints differ in case and suffix -- and only when
+    the table was measured on a build of the present kernel sources (its source_hash)."""
     import importlib.util
+    import json
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+        table = json.load(fh)
+    name = "lbm2_kernel<float, lt::d3q19, 0, 1, 64, 8, 1, false, 1>"
+    # a table from other kernel sources is not used
+    monkeypatch.setattr(bench, "source_hash", lambda: "not-the-hash-of-the-table")
+    assert bench.traffic_from_profile(name) is None
     # the dominant kernel of the default bench run: two lattice updates per launch, so the HBM bytes
     # of a launch are about half the algorithmic bytes of the two updates
-    name = "lbm2_kernel<float, lt::d3q19, 0, 1, 64, 8, 1, false, 1>"
+    monkeypatch.setattr(bench, "source_hash", lambda: table.get("source_hash"))
     traffic = bench.traffic_from_profile(name)
     assert traffic is not None
     assert 0.45 < traffic / (2 * 152 * 256 ** 3) < 0.6

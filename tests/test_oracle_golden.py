@@ -54,6 +54,23 @@ def test_tgv_initial_condition_and_steps(name, lat, coll, dt, snaps):
         assert e == pytest.approx(ref[i], rel=1e-12 if dt == "f64" else 2e-6)
 
 
+@pytest.mark.parametrize("name,lat,coll,dt,snaps", TGV, ids=[t[0] for t in TGV])
+def test_enstrophy_and_mass_observables(name, lat, coll, dt, snaps):
+    """The reference's Enstrophy and Mass observables at step 0 and at the stored snapshots."""
+    g = golden(name)
+    steps = g["energy_steps"].tolist()
+    lattice = orc.LATTICES[lat]
+    res = [int(r) for r in g["resolution"]]
+    units = orc.tgv_units(res, float(g["reynolds"]), float(g["mach"]))
+    for i in [0] + [n for n in snaps if n in steps]:
+        f = torch.as_tensor(g[f"f{i}"])
+        at = steps.index(i)
+        assert float(orc.enstrophy_pu(f, lattice, units)) == pytest.approx(float(g["enstrophy_pu"][at]),
+                                                                           rel=1e-12 if dt == "f64" else 1e-5)
+        assert float(orc.mass_observable(f)) == pytest.approx(float(g["mass_observable"][at]),
+                                                              rel=1e-13 if dt == "f64" else 1e-6)
+
+
 def test_cfg1_anchor_energies():
     """SURVEY.md 8(c) anchors for examples/00_simplest_TGV.py (128^2 fp64)."""
     g = golden("tgv2d_d2q9_bgk_128_f64")
