@@ -231,6 +231,17 @@ int lt_mass(lt_plan *plan, const void *f_dev, double *out_dev, void *stream);
  * lettuce/ext/_reporter/observable_reporter.py:27-31; the pu scaling stays on the host). */
 int lt_max_velocity(lt_plan *plan, const void *f_dev, double *out_dev, void *stream);
 
+/* Non-equilibrium initialisation (lettuce/_flow.py:309-336, Krueger et al. 2017): f_dev [q][N] =
+ * feq(rho, u) - w_q Pi1:Q_q with Pi1_ab = tau rho d_b u_a / cs^2 from the 6th-order periodic central
+ * differences of torch_gradient (util/utility.py:37-99, dx = 1) and Q_q,ab = e_qa e_qb - identity_cs2
+ * delta_ab.  identity_cs2 is passed by the caller because the reference builds the identity in torch's
+ * DEFAULT dtype (an fp32-rounded cs^2 even in an fp64 run, _flow.py:328-330).  rho_dev [N] and u_dev
+ * [d][N] (lattice units, logical component order) are the moments of the equilibrium populations, as
+ * Flow.rho() / Flow.u() give them; one launch, nothing else is materialised (the reference builds
+ * [d][d][N] gradients, Pi1 and two [q][N] fields).  Reference layout, periodic along every axis. */
+int lt_init_fneq(lt_plan *plan, const void *rho_dev, const void *u_dev, double tau, double identity_cs2,
+                 void *f_dev, void *stream);
+
 /* Enstrophy observable (lettuce/ext/_reporter/observable_reporter.py:45-68): *out_dev = sum over nodes
  * of |curl(u_scale * u)|^2 with the 6th-order periodic central differences of torch_gradient
  * (lettuce/util/utility.py:37-99; weights -1/60, 3/20, -3/4, 3/4, -3/20, 1/60 times inv_dx), evaluated

@@ -247,9 +247,17 @@ def local_contract(matrix: torch.Tensor, field: torch.Tensor) -> torch.Tensor:
 def initialize_f_neq(flow: "Flow"):
     """f = feq - f(1), the non-equilibrium part estimated from 6th-order finite differences
     of u (lettuce/_flow.py:309-336; Krueger et al. 2017)."""
+    d = flow.stencil.d
+    plan = flow._engine_plan(flow.f) if d >= 2 else None
+    if plan is not None:
+        # one launch of the engine (lt_init_fneq): the moments of the equilibrium populations, then
+        # gradients, Pi1:Q and feq per node -- no [d, d, *res] / [q, *res] temporaries, no BLAS.
+        # The reference's identity is built in torch's default dtype: an fp32-rounded cs^2.
+        rho, u = plan.macroscopic(flow.f)
+        eye_cs2 = float(torch.tensor(flow.stencil.cs ** 2, dtype=torch.get_default_dtype()))
+        return plan.init_fneq(rho, u, flow.units.relaxation_parameter_lu, eye_cs2)
     rho = flow.rho()
     u = flow.u()
-    d = flow.stencil.d
     grad_u = torch.cat([torch_gradient(u[a], dx=1, order=6)[None, ...] for a in range(d)])
     pi_1 = 1.0 * flow.units.relaxation_parameter_lu * rho * grad_u / flow.torch_stencil.cs ** 2
     e = flow.torch_stencil.e

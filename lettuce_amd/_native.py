@@ -82,6 +82,7 @@ SYMBOLS = {
     "lt_kinetic_energy": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "lt_mass": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "lt_max_velocity": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "lt_init_fneq": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _dbl, _vp, _vp]),
     "lt_enstrophy": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _dbl, _vp, _vp]),
     "lt_mass_interior": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "lt_plan_kernel_info": (ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i32),
@@ -420,6 +421,20 @@ class Plan:
         out = torch.empty((), dtype=torch.float64, device=f.device)
         self._check(self.lib.lt_max_velocity(self._handle, _ptr(f), _ptr(out), _stream_handle()))
         return out
+
+    @_on_device
+    def init_fneq(self, rho, u, tau: float, identity_cs2: float):
+        """feq(rho, u) - f_neq(grad u) in one launch (initialize_f_neq); rho [*res] or [1, *res], u [d, *res]"""
+        grid = self.f_shape[1:]
+        rho = rho.reshape(grid).contiguous()
+        u = u.contiguous()
+        self._tensor_ok(rho, grid); self._tensor_ok(u, [self.d] + grid)
+        f = torch.empty(self.f_shape, dtype=self.dtype, device=rho.device)
+        self._check(self.lib.lt_init_fneq(self._handle, _ptr(rho), _ptr(u), float(tau), float(identity_cs2), _ptr(f),
+                                          _stream_handle()))
+        for t in (rho, u):
+            t.record_stream(torch.cuda.current_stream())
+        return f
 
     @_on_device
     def enstrophy_sum(self, f, u_scale: float, inv_dx: float):

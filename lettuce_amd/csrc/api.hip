@@ -727,6 +727,13 @@ int lt_max_velocity(lt_plan *p, const void *f, double *out, void *s) {
   return aux(p, 4, f, nullptr, nullptr, out, s);
 }
 
+int lt_init_fneq(lt_plan *p, const void *rho, const void *u, double tau, double identity_cs2, void *f, void *s) {
+  if (!rho || !u) return fail(LT_ERR_INVALID, "null rho/u");
+  if (p && (p->unit.d < 2 || p->desc.layout != LT_LAYOUT_REFERENCE || p->desc.ghost_planes))
+    return fail(LT_ERR_UNSUPPORTED, "f_neq initialisation: 2-D / 3-D grids in the reference layout");
+  if (!(tau > 0.0)) return fail(LT_ERR_INVALID, "relaxation time tau = %g", tau);
+  return aux(p, 7, f, const_cast<void *>(rho), const_cast<void *>(u), nullptr, s, tau, identity_cs2);
+}
 int lt_enstrophy(lt_plan *p, const void *f, void *u_scratch, double u_scale, double inv_dx, double *out, void *s) {
   if (!out || !u_scratch) return fail(LT_ERR_INVALID, "null output / scratch");
   if (p && (p->unit.d < 2 || p->desc.layout != LT_LAYOUT_REFERENCE || p->desc.ghost_planes))

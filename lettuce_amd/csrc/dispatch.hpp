@@ -30,7 +30,8 @@ struct StepArgs {
 };
 
 struct AuxArgs {
-  int what;              // 0 macroscopic, 1 equilibrium, 2 kinetic energy, 3 mass, 4 max |u|, 5 enstrophy, 6 interior mass
+  int what;              // 0 macroscopic, 1 equilibrium, 2 kinetic energy, 3 mass, 4 max |u|, 5 enstrophy, 6 interior mass,
+                         // 7 f_neq initialisation (scale = tau, inv_dx = the identity's cs^2)
   int layout;
   const void *f;         // populations (what 0, 2, 3) / feq output (what 1; cast away const)
   void *rho;             // what 0: out, what 1: in

@@ -1107,6 +1107,72 @@ __global__ void __launch_bounds__(kThreads) equilibrium_kernel(const T *__restri
   });
 }
 
+// f = feq(rho, u) - w_q Pi1:Q_q  -- initialize_f_neq (lettuce/_flow.py:309-336), reference layout,
+// periodic.  S[a][b] = d u_a / d x_b: torch_gradient's 6th-order central differences (dx = 1), term
+// order of the reference's expression; Pi1 = ((1.0 tau) rho) S / cs^2; Q_q,ab = e_qa e_qb - eye_cs2 d_ab.
+template <typename T, class S>
+__global__ void __launch_bounds__(kThreads) fneq_kernel(const T *__restrict__ rho_in, const T *__restrict__ u_in,
+                                                       T *__restrict__ f_out, int n0, int n1, int n2, T tau,
+                                                       T eye_cs2) {
+#pragma clang fp contract(off)
+  using M = MemMap<S, 0>;
+  constexpr int D = S::D;
+  const long long N = (long long)n0 * n1 * n2;
+  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= N) return;
+  const int c0 = (int)(i % n0), c1 = (int)((i / n0) % n1), c2 = (int)(i / ((long long)n0 * n1));
+  const T w6[6] = {T(-1. / 60.), T(3. / 20.), T(-3. / 4.), T(3. / 4.), T(-3. / 20.), T(1. / 60.)};
+  const int sh[6] = {3, 2, 1, -1, -2, -3};
+  T grad[D][D];                                   // [component a][logical axis b]
+#pragma unroll
+  for (int b = 0; b < D; ++b) {
+    const int m = D - 1 - b;                      // memory axis of logical axis b
+    long long at[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      int a0 = c0, a1 = c1, a2 = c2;
+      if (m == 0) { a0 = c0 - sh[k]; a0 = a0 < 0 ? a0 + n0 : (a0 >= n0 ? a0 - n0 : a0); }
+      if (m == 1) { a1 = c1 - sh[k]; a1 = a1 < 0 ? a1 + n1 : (a1 >= n1 ? a1 - n1 : a1); }
+      if (m == 2) { a2 = c2 - sh[k]; a2 = a2 < 0 ? a2 + n2 : (a2 >= n2 ? a2 - n2 : a2); }
+      at[k] = ((long long)a2 * n1 + a1) * n0 + a0;
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      const T *uc = u_in + (long long)a * N;
+      T r = w6[0] * uc[at[0]];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) r = r + w6[k] * uc[at[k]];
+      grad[a][b] = r;
+    }
+  }
+  const T rho = rho_in[i];
+  const T scale = (T(1.0) * tau) * rho;
+  const T cs2 = (T)kCs2;
+  T pi[D][D];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b < D; ++b) pi[a][b] = scale * grad[a][b] / cs2;
+  T u[3] = {T(0), T(0), T(0)};
+#pragma unroll
+  for (int a = 0; a < D; ++a) u[M::memory(a)] = u_in[(long long)a * N + i];
+  const T uxu = square_norm<S, 0>(u);
+  for_each_feq<T, S, 0>(rho, u, uxu, [&](auto qc, T feq) {
+    constexpr int q = decltype(qc)::value;
+    T acc = T(0);
+    static_for<D>([&](auto ac) {
+      constexpr int a = decltype(ac)::value;
+      static_for<D>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        constexpr int ee = S::E[q][a] * S::E[q][b];
+        const T qab = a == b ? T(ee) - eye_cs2 : T(ee);
+        acc = acc + pi[a][b] * qab;
+      });
+    });
+    f_out[(long long)q * N + i] = feq - T(S::W[q]) * acc;
+  });
+}
+
 // wavefront (64-lane) + workgroup reduction of a double (sum, or max when MAX); result valid in
 // thread 0
 template <bool MAX = false>

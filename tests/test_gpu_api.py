@@ -398,6 +398,43 @@ def test_full_size_cfg3_slab_equals_single_domain():
     assert sim_s.kinetic_energy_pu() == pytest.approx(float(lt.IncompressibleKineticEnergy(fl_p)()), rel=1e-6)
 
 
+def test_fneq_initialisation_kernel_against_the_reference_expression_on_random_fields():
+    """lt_init_fneq against the oracle's restatement of initialize_f_neq (_flow.py:309-336) on random smooth
+    fields, 2-D and 3-D, fp64: rounding level."""
+    from oracle import lettuce_oracle as orc
+    torch.manual_seed(11)
+    for stencil, res in ((lt.D2Q9, [12, 9]), (lt.D3Q19, [8, 7, 10]), (lt.D3Q27, [7, 8, 9]), (lt.D3Q15, [8, 8, 8])):
+        st = stencil()
+        flow = lt.TaylorGreenVortex(gpu("f64"), res if st.d == 3 else res, 100, 0.05, st, initialize_fneq=False)
+        rho = 1 + 0.01 * torch.rand([1] + res, dtype=torch.float64)
+        u = 0.05 * torch.rand([st.d] + res, dtype=torch.float64)
+        e, w = orc.lattice_tensors(orc.LATTICES[stencil.__name__], torch.float64)
+        f_eq = orc.quadratic_equilibrium(rho, u, e, w)
+        flow.f = f_eq.cuda()
+        from lettuce_amd._flow import initialize_f_neq
+        got = initialize_f_neq(flow).cpu()
+        # non-native expression of the mirror on the CPU (validated against the reference's f0 vectors)
+        cpu_flow = lt.TaylorGreenVortex(lt.Context("cpu", torch.float64, use_native=False), res, 100, 0.05, stencil(),
+                                        initialize_fneq=False)
+        cpu_flow.f = f_eq.clone()
+        want = initialize_f_neq(cpu_flow)
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=2e-16 * float(want.abs().max()) * 8)
+
+
+def test_device_contraction_without_blas_at_the_slab_shape_that_faulted():
+    """Regression for the round-1 fault: per-node contractions of a 512 x 512 x 70 fp32
+    slab went through torch's einsum -> GEMM (19 x 9 times 9 x 18.35 M) and faulted inside the BLAS kernel.
+    Device tensors do not go through BLAS any more; local_contract at that very shape against CPU einsum."""
+    from lettuce_amd._flow import local_contract
+    torch.manual_seed(2)
+    n = 512 * 512 * 70
+    m = torch.rand(19, 9)
+    field = torch.rand(9, n)
+    want = torch.einsum("ik,kx->ix", m, field)
+    got = local_contract(m.cuda(), field.cuda().reshape(9, 512, 512, 70)).reshape(19, n).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=2e-6)
+
+
 def test_long_run_energy_decay_fp32_tracks_fp64():
     """1000 steps of TGV3D D3Q19 at 64^3 on the HIP engine: the fp32 kinetic-energy series decays
     monotonically and stays within 3e-4 of the fp64 series.  The gap is the reference's own: its
@@ -445,13 +482,17 @@ def test_integration_md_ctypes_stub_steps_a_simulation():
     np.testing.assert_allclose(flow.f.cpu().numpy(), g["f10"], rtol=0, atol=1e-5 * float(np.abs(g["f10"]).max()))
 
 
-def test_engine_kernel_name_matches_the_committed_traffic_profile():
-    """the name bench.py looks up in profiles/traffic.json is the one the 256^3 plan reports"""
+def test_engine_kernel_name_matches_the_committed_traffic_profile(monkeypatch):
+    """the name bench.py looks up in profiles/traffic.json is the one the 256^3 plan reports (whether the
+    table belongs to this build of the kernel sources is a separate question: its source_hash)"""
     import importlib.util
+    import json
     from conftest import ROOT
     from lettuce_amd._native import Plan
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+        monkeypatch.setattr(bench, "source_hash", lambda h=json.load(fh).get("source_hash"): h)
     plan = Plan("D3Q19", torch.float32, "bgk", [256, 256, 256], [], device=torch.device("cuda:0"))
     assert bench.traffic_from_profile(plan.kernel_name()) is not None
