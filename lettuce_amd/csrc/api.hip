@@ -94,6 +94,8 @@ struct lt_plan {
   void *bt = nullptr;        // BoundaryTable<T>
   double *partial = nullptr;
   int masked = 0;
+  int nsm_confined = 1;      // every no-streaming bit lies on the anti-bounce-back outlet's plane (lt_plan_set_masks)
+  unsigned *mask_flag = nullptr;   // device word written by the mask compilation
   char kernel_name[192];
   // launch-bound grids: a captured hipGraph of kGraphChunk fused steps (ping-pong returns to the
   // starting buffer), replayed on a plan-owned stream that is forked from / joined to the caller's
@@ -248,13 +250,13 @@ TwoStepTile two_step_tile(const lt_plan *p) {
 // whole rounds): 128 planes = 256 workgroups at 256^3 (measured 0.3345 ms per step against 0.3412
 // with 32 planes and 0.52 with 256, which leaves half the CUs idle).
 int resolve_seg_len(const lt_plan *p, int planes) {
-  if (p->seg_len > 0) return p->seg_len;
+  if (p->seg_len > (p->masked ? 1 : 0)) return p->seg_len;
   const TwoStepTile tile = two_step_tile(p);
   const long long tiles = (long long)(p->n0 / tile.width) * (p->n1 / (tile.rows ? tile.rows : 8));
   const long long cus = p->n_cu > 0 ? p->n_cu : 256;
   int best = 1;
   double best_score = -1.0;
-  for (int len = 1; len <= planes; ++len) {
+  for (int len = p->masked ? 2 : 1; len <= planes; ++len) {   // masked: the outlet's plane never opens a segment
     const long long segs = (planes + len - 1) / len;
     if (!p->desc.ghost_planes && planes % len) continue;   // keep whole-grid launches evenly cut
     const long long blocks = tiles * segs;
@@ -303,6 +305,24 @@ int halo2(lt_plan *p, bool do_pack, void *f, int side, void *buf, void *stream) 
   return LT_OK;
 }
 
+// Two updates per launch on a plan with boundaries (lbm2m_kernel, twostep_masked.hpp): bounce-back and
+// equilibrium nodes anywhere; an anti-bounce-back outlet only at the LAST plane of the sweep axis (memory
+// axis a2, side +1 -- the reference's Obstacle in the reference layout), where its neighbour's moments and
+// its no-streaming bits reduce to tests on the plane index; and no-streaming bits exactly where that
+// outlet puts them (checked on the device when the masks are compiled).  Anything else keeps the one-step
+// kernel.
+bool masked_two_step_ok(const lt_plan *p) {
+  if (!p->nsm_confined) return false;
+  int n_abb = 0;
+  for (int i = 0; i < p->desc.n_boundaries; ++i) {
+    const lt_boundary_desc &b = p->desc.boundaries[i];
+    if (b.kind != LT_BOUNDARY_ABB_OUTLET) continue;
+    if (++n_abb > 1) return false;
+    if (mem_axis_of(p, b.axis) != 2 || b.side != 1 || p->n2 < 3) return false;
+  }
+  return true;
+}
+
 int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long pb, long long pe,
          void *stream, long long stride = 1, void *pack_lo = nullptr, void *pack_hi = nullptr) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
@@ -323,7 +343,10 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
       return fail(LT_ERR_INVALID, "two-step range [%lld, %lld) must stay in [2, %d)", pb, pe, p->n2 - 2);
     if (!p->desc.ghost_planes && (pb != 0 || pe != p->n2))
       return fail(LT_ERR_INVALID, "periodic plan: the two-step launch covers all planes");
-    if (p->masked) return fail(LT_ERR_UNSUPPORTED, "two steps per launch: no masks / boundaries");
+    if (p->masked && (p->desc.ghost_planes || !masked_two_step_ok(p)))
+      return fail(LT_ERR_UNSUPPORTED, "two steps per launch with boundaries: periodic plans whose only anti-bounce-back "
+                                      "outlet (if any) is at the last plane of the slowest memory axis, no-streaming "
+                                      "bits exactly that outlet's");
   }
   if (p->desc.n_boundaries > 0 && !p->masked)
     return fail(LT_ERR_INVALID, "plan has boundaries but lt_plan_set_masks was not called");
@@ -424,12 +447,14 @@ long long run_graph(lt_plan *p, void *cur, void *other, double tau, long long fu
 // (asked of the unit by name), a grid that tiles (a0 % 64, a1 % 8) and no masks; "automatic" also
 // asks for the streaming regime (populations beyond the caches), where halving the HBM passes pays.
 bool two_step_wanted(lt_plan *p) {
-  if (p->two_step == 0 || p->masked || p->desc.ghost_planes) return false;
+  if (p->two_step == 0 || p->desc.ghost_planes) return false;
+  if (p->masked && !masked_two_step_ok(p)) return false;
   const TwoStepTile tile = two_step_tile(p);
   if (tile.rows == 0 || p->n0 % tile.width != 0 || p->n1 % tile.rows != 0) return false;
   lt::StepArgs a;
   memset(&a, 0, sizeof a);
   a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = lt::kFusedTwice;
+  a.masked = p->masked;
   if (!p->unit.name(a)) return false;
   if (p->two_step == 1) return true;
   const long long bytes = 2ll * p->unit.q * p->N * p->esize;
@@ -623,6 +648,7 @@ int lt_plan_destroy(lt_plan *p) {
   if (p->node) (void)hipFree(p->node);
   if (p->nsm_bits) (void)hipFree(p->nsm_bits);
   if (p->bt) (void)hipFree(p->bt);
+  if (p->mask_flag) (void)hipFree(p->mask_flag);
   if (p->partial) (void)hipFree(p->partial);
   if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
   if (p->gev_in) (void)hipEventDestroy(p->gev_in);
@@ -642,11 +668,29 @@ int lt_plan_set_masks(lt_plan *p, const uint8_t *ncm, const uint8_t *nsm, void *
   }
   if (!p->node) LT_HIP(hipMalloc((void **)&p->node, (size_t)p->N));
   if (nsm && !p->nsm_bits) LT_HIP(hipMalloc((void **)&p->nsm_bits, (size_t)p->N * sizeof(unsigned)));
+  if (!p->mask_flag) LT_HIP(hipMalloc((void **)&p->mask_flag, sizeof(unsigned)));
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  LT_HIP(hipMemsetAsync(p->mask_flag, 0, sizeof(unsigned), hs));
+  // the only no-streaming bits the two-step kernel can take: those of an outlet at the last plane of the
+  // slowest memory axis -- the populations moving down that axis, on every node of that plane
+  int plane = -1;
+  unsigned expected = 0;
+  for (int i = 0; i < p->desc.n_boundaries; ++i) {
+    const lt_boundary_desc &b = p->desc.boundaries[i];
+    if (b.kind == LT_BOUNDARY_ABB_OUTLET && mem_axis_of(p, b.axis) == 2 && b.side == 1) {
+      plane = p->n2 - 1;
+      const lt::QList down = crossing(p, -1);
+      for (int k = 0; k < down.n; ++k) expected |= 1u << down.q[k];
+    }
+  }
   const unsigned grid = (unsigned)((p->N + lt::kThreads - 1) / lt::kThreads);
-  hipLaunchKernelGGL(lt::compile_masks_kernel, dim3(grid), dim3(lt::kThreads), 0,
-                     static_cast<hipStream_t>(stream), ncm, nsm, p->unit.q, p->N, p->node,
-                     nsm ? p->nsm_bits : nullptr);
+  hipLaunchKernelGGL(lt::compile_masks_kernel, dim3(grid), dim3(lt::kThreads), 0, hs, ncm, nsm, p->unit.q, p->N,
+                     p->node, nsm ? p->nsm_bits : nullptr, (long long)p->n0 * p->n1, plane, expected, p->mask_flag);
   LT_HIP(hipGetLastError());
+  unsigned outside = 0;
+  LT_HIP(hipMemcpyAsync(&outside, p->mask_flag, sizeof outside, hipMemcpyDeviceToHost, hs));
+  LT_HIP(hipStreamSynchronize(hs));
+  p->nsm_confined = outside == 0;
   p->masked = 1;
   return LT_OK;
 }
@@ -768,8 +812,8 @@ const char *lt_plan_kernel_name(lt_plan *p) {
   // ghost planes
   a.mode = (two_step_wanted(p) || p->desc.ghost_planes == 2) ? lt::kFusedTwice : lt::kFused;
   if (many_step_wanted(p)) a.mode = lt::kFusedMany;
-  if (a.mode == lt::kFusedTwice && !p->unit.name(a)) a.mode = lt::kFused;
   a.masked = p->masked;
+  if (a.mode == lt::kFusedTwice && !p->unit.name(a)) a.mode = lt::kFused;
   a.wide = (p->want_wide && p->wide_ok && !a.masked && a.coll == LT_COLLISION_BGK) ? 1 : 0;
   a.shift = a.wide ? p->shift : 0;
   a.tune = resolve_tune(p, a.wide);

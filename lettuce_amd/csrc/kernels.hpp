@@ -554,25 +554,12 @@ __device__ __forceinline__ void bounce_back(T (&f)[S::Q][VEC]) {
   });
 }
 
-// (rho, j) of the node next to an outlet plane, as Flow.rho()/Flow.u() would see it when the
-// AntiBounceBackOutlet with index `slot` is evaluated: after collision (which conserves both)
-// and after the boundaries with a lower index (anti_bounce_back_outlet.py:77-80).
-template <typename T, class S, int LAYOUT, bool STREAM, bool MASKED>
-__device__ __forceinline__ void neighbour_moments(const KParams<T> &p, int c0, int c1, int c2, int slot,
-                                  T &rho, T (&j)[3]) {
-  const Coord c = make_coord(p, c0, c1, c2);
-  T g[S::Q][1];
-  gather<T, S, LAYOUT, STREAM, 1, 0>(p, c, g);
-  const unsigned own = (unsigned)(c2 * p.n1 + c1) * (unsigned)p.n0 + (unsigned)c0;
-  int b = 0;
-  if constexpr (MASKED) {
-    const unsigned char nd = p.node[own];
-    b = nd & 0x7f;
-    if constexpr (STREAM) {
-      if (nd & 0x80) keep_unstreamed<T, S, 1, 0>(p, own, g);
-    }
-  }
-  moments<T, S, LAYOUT, 1, 0>(g, rho, j);
+// What the boundaries with an index below `slot` do to (rho, j) of a node whose no_collision_mask index
+// is b (collision conserves both): bounce-back negates j, an equilibrium boundary replaces the moments
+// by those of its populations (neighbour_moments; also the two-step kernel's phase B)
+template <typename T, class S, int LAYOUT>
+__device__ __forceinline__ void lower_boundaries_on_moments(const KParams<T> &p, int b, int slot, unsigned own,
+                                                            T &rho, T (&j)[3]) {
   if (b > 0 && b < slot) {
     const int kind = p.bt->kind[b];
     if (kind == kBounceBack) {
@@ -590,17 +577,37 @@ __device__ __forceinline__ void neighbour_moments(const KParams<T> &p, int c0, i
   }
 }
 
+// (rho, j) of the node next to an outlet plane, as Flow.rho()/Flow.u() would see it when the
+// AntiBounceBackOutlet with index `slot` is evaluated: after collision (which conserves both)
+// and after the boundaries with a lower index (anti_bounce_back_outlet.py:77-80).
+template <typename T, class S, int LAYOUT, bool STREAM, bool MASKED>
+__device__ __forceinline__ void neighbour_moments(const KParams<T> &p, int c0, int c1, int c2, int slot,
+                                                  T &rho, T (&j)[3]) {
+  const Coord c = make_coord(p, c0, c1, c2);
+  T g[S::Q][1];
+  gather<T, S, LAYOUT, STREAM, 1, 0>(p, c, g);
+  const unsigned own = (unsigned)(c2 * p.n1 + c1) * (unsigned)p.n0 + (unsigned)c0;
+  int b = 0;
+  if constexpr (MASKED) {
+    const unsigned char nd = p.node[own];
+    b = nd & 0x7f;
+    if constexpr (STREAM) {
+      if (nd & 0x80) keep_unstreamed<T, S, 1, 0>(p, own, g);
+    }
+  }
+  moments<T, S, LAYOUT, 1, 0>(g, rho, j);
+  lower_boundaries_on_moments<T, S, LAYOUT>(p, b, slot, own, rho, j);
+}
+
 // AntiBounceBackOutlet (lettuce/ext/_boundary/anti_bounce_back_outlet.py:72-91) on one node
-// of the outlet plane.
-template <typename T, class S, int LAYOUT, bool STREAM, bool MASKED, int VEC, int k>
-__device__ __forceinline__ void abb_outlet(const KParams<T> &p, int slot, int c0k, int c1,
-                                           int c2, T (&f)[S::Q][VEC]) {
+// of the outlet plane, given (rho, j) of the node next to it (neighbour_moments).
+template <typename T, class S, int LAYOUT, int VEC, int k>
+__device__ __forceinline__ void abb_apply(const KParams<T> &p, int slot, T rn, const T (&jn)[3],
+                                          T (&f)[S::Q][VEC]) {
   using M = MemMap<S, LAYOUT>;
-  const int ax = p.bt->mem_axis[slot], side = p.bt->side[slot], nbr = p.bt->nbr[slot];
-  T rho, j[3], rn, jn[3];
+  const int ax = p.bt->mem_axis[slot], side = p.bt->side[slot];
+  T rho, j[3];
   moments<T, S, LAYOUT, VEC, k>(f, rho, j);
-  neighbour_moments<T, S, LAYOUT, STREAM, MASKED>(p, ax == 0 ? nbr : c0k, ax == 1 ? nbr : c1,
-                                                   ax == 2 ? nbr : c2, slot, rn, jn);
   T uw[3];
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
@@ -621,6 +628,45 @@ __device__ __forceinline__ void abb_outlet(const KParams<T> &p, int slot, int c0
     const int en = (ax == 0 ? M::e(q, 0) : (ax == 1 ? M::e(q, 1) : M::e(q, 2))) * side;
     if (en == 1) f[S::OPP[q]][k] = fresh[q];
   });
+}
+
+template <typename T, class S, int LAYOUT, bool STREAM, bool MASKED, int VEC, int k>
+__device__ __forceinline__ void abb_outlet(const KParams<T> &p, int slot, int c0k, int c1,
+                                           int c2, T (&f)[S::Q][VEC]) {
+  const int ax = p.bt->mem_axis[slot], nbr = p.bt->nbr[slot];
+  T rn, jn[3];
+  neighbour_moments<T, S, LAYOUT, STREAM, MASKED>(p, ax == 0 ? nbr : c0k, ax == 1 ? nbr : c1,
+                                                   ax == 2 ? nbr : c2, slot, rn, jn);
+  abb_apply<T, S, LAYOUT, VEC, k>(p, slot, rn, jn, f);
+}
+
+// The boundaries of one node in index order (lettuce/_simulation.py:183-188); b = the node's index in
+// no_collision_mask, (c0k, c1, c2) its memory coordinates, ownk its index within a population.
+template <typename T, class S, int LAYOUT, bool STREAM, int VEC, int k>
+__device__ __forceinline__ void apply_boundaries(const KParams<T> &p, int b, int c0k, int c1, int c2,
+                                                 unsigned ownk, T (&f)[S::Q][VEC]) {
+  for (int slot = 1; slot <= p.nb; ++slot) {
+    const int kind = p.bt->kind[slot];
+    if (kind == kAbbOutlet) {
+      // applies on the whole outlet plane, whatever the node's index: the reference
+      // mutates flow.f in place and the masked torch.where is then a no-op
+      // (anti_bounce_back_outlet.py:81-91, _simulation.py:186-188)
+      const int ax = p.bt->mem_axis[slot];
+      const int coord = ax == 0 ? c0k : (ax == 1 ? c1 : c2);
+      if (coord == p.bt->plane[slot])
+        abb_outlet<T, S, LAYOUT, STREAM, true, VEC, k>(p, slot, c0k, c1, c2, f);
+    } else if (b == slot) {
+      if (kind == kBounceBack) {
+        bounce_back<T, S, VEC, k>(f);
+      } else if (kind == kEquilibrium) {
+        const T *fld = p.bt->field[slot];
+        static_for<S::Q>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          f[q][k] = fld ? fld[(long long)q * p.N + ownk] : p.bt->feq[slot][q];
+        });
+      }
+    }
+  }
 }
 
 // ---- the kernel ---------------------------------------------------------------------------
@@ -680,30 +726,8 @@ __device__ __forceinline__ void lbm_body(const KParams<T> &p) {
         if constexpr (COLL == 1) collide_bgk<T, S, LAYOUT, VEC, k>(f, p.tau_inv);
         if constexpr (COLL == 2) collide_kbc<T, S, LAYOUT, VEC, k>(f, p.beta, p.inv_beta);
       }
-      if constexpr (MASKED) {
-        for (int slot = 1; slot <= p.nb; ++slot) {
-          const int kind = p.bt->kind[slot];
-          if (kind == kAbbOutlet) {
-            // applies on the whole outlet plane, whatever the node's index: the reference
-            // mutates flow.f in place and the masked torch.where is then a no-op
-            // (anti_bounce_back_outlet.py:81-91, _simulation.py:186-188)
-            const int ax = p.bt->mem_axis[slot];
-            const int coord = ax == 0 ? c0 + k : (ax == 1 ? c1 : c2);
-            if (coord == p.bt->plane[slot])
-              abb_outlet<T, S, LAYOUT, STREAM, MASKED, VEC, k>(p, slot, c0 + k, c1, c2, f);
-          } else if (b == slot) {
-            if (kind == kBounceBack) {
-              bounce_back<T, S, VEC, k>(f);
-            } else if (kind == kEquilibrium) {
-              const T *fld = p.bt->field[slot];
-              static_for<S::Q>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-                f[q][k] = fld ? fld[(long long)q * p.N + own + k] : p.bt->feq[slot][q];
-              });
-            }
-          }
-        }
-      }
+      if constexpr (MASKED)
+        apply_boundaries<T, S, LAYOUT, STREAM, VEC, k>(p, b, c0 + k, c1, c2, own + k, f);
     });
   }
 
@@ -1348,9 +1372,12 @@ __global__ void __launch_bounds__(kThreads) halo2_kernel(T *__restrict__ f, T *_
 }
 
 // node descriptor byte + sparse streaming-mask bits from the reference's two mask tensors
+// *mismatch is set when the no-streaming bits of a node differ from `expected` on a2 plane `plane` or
+// from zero elsewhere (the masked two-step kernel's admission test; plane < 0: no bits anywhere)
 static __global__ void __launch_bounds__(kThreads) compile_masks_kernel(
     const unsigned char *__restrict__ ncm, const unsigned char *__restrict__ nsm, int q,
-    long long N, unsigned char *__restrict__ node, unsigned *__restrict__ bits) {
+    long long N, unsigned char *__restrict__ node, unsigned *__restrict__ bits, long long plane_nodes, int plane,
+    unsigned expected, unsigned *__restrict__ mismatch) {
   const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (i >= N) return;
   unsigned b = 0;
@@ -1360,6 +1387,7 @@ static __global__ void __launch_bounds__(kThreads) compile_masks_kernel(
   }
   node[i] = (unsigned char)((ncm ? (ncm[i] & 0x7f) : 0) | (b ? 0x80 : 0));
   if (bits) bits[i] = b;
+  if (b != ((plane >= 0 && i / plane_nodes == plane) ? expected : 0u)) *mismatch = 1u;
 }
 
 }  // namespace lt

@@ -468,6 +468,115 @@ def test_abb_outlet_after_lower_index_boundaries(lat, res, axis, side):
     np.testing.assert_allclose(got, sim.f.numpy(), rtol=0, atol=1e-12)
 
 
+# --------------------------------------------------------------------------- two steps per launch, with boundaries
+def _masked_case(lat, res, dtype, abb, seed, with_field=False, abb_first=False):
+    """Random bounce-back and equilibrium nodes (the latter optionally with a per-node field) plus one
+    anti-bounce-back outlet (axis, side) with the masks the reference's boundary builds; abb = None: no outlet."""
+    L = orc.LATTICES[lat]
+    g = torch.Generator().manual_seed(seed)
+    f0 = _random_state(L, res, dtype, seed)
+    e, w = orc.lattice_tensors(L, dtype)
+    bb_mask = torch.rand(res, generator=g) < 0.2
+    eq_mask = (torch.rand(res, generator=g) < 0.15) & ~bb_mask
+    units = orc.Units(10, 0.1)
+    vel = torch.tensor([0.2, 0.1, -0.3][:L.d], dtype=dtype)
+    feq = orc.quadratic_equilibrium(units.pressure_pu_to_density_lu(torch.tensor(0.01, dtype=dtype)),
+                                    units.velocity_to_lu(vel), e, w)
+    ncm = torch.zeros(res, dtype=torch.uint8)
+    nsm = torch.zeros([L.q] + res, dtype=torch.uint8)
+    entries = [{"kind": "bounce_back"}, {"kind": "equilibrium", "feq": feq.double().tolist()}]
+    if with_field:
+        field = (feq.reshape([-1] + [1] * len(res)) * (1 + 0.1 * torch.rand([L.q] + res, generator=g, dtype=torch.float64))).to(dtype)
+        entries[1] = {"kind": "equilibrium", "field": field.cuda()}
+    m = None
+    if abb is not None:
+        axis, side = abb
+        direction = [0] * L.d
+        direction[axis] = side
+        m, sm = orc.abb_masks(f0.shape, orc.OracleBoundary("abb_outlet", direction=direction), L)
+        nsm |= sm.to(torch.uint8)
+        entry = {"kind": "abb_outlet", "axis": axis, "side": side}
+        entries = [entry] + entries if abb_first else entries + [entry]
+    # later boundaries overwrite earlier ones in no_collision_mask (_simulation.py:63-86)
+    for index, e_ in enumerate(entries, start=1):
+        ncm[{"bounce_back": bb_mask, "equilibrium": eq_mask}.get(e_["kind"], m)] = index
+    return f0, ncm, nsm, entries
+
+
+MASKED_TWO_STEP = [("D3Q19", [8, 16, 64], "f32", (0, 1)), ("D3Q19", [8, 16, 64], "f32", (0, -1)), ("D3Q19", [6, 8, 128], "f32", (1, 1)),
+                   ("D3Q19", [6, 16, 64], "f32", (0, 1)), ("D3Q19", [7, 8, 64], "f32", (0, 1)), ("D3Q19", [4, 8, 64], "f32", (2, -1)),
+                   ("D3Q19", [5, 8, 64], "f32", None), ("D3Q27", [6, 8, 64], "f32", (0, 1)), ("D3Q27", [5, 4, 64], "f32", None),
+                   ("D3Q15", [6, 8, 64], "f32", (0, 1)), ("D3Q15", [6, 8, 32], "f64", (0, 1)), ("D3Q15", [5, 8, 32], "f64", None)]
+
+
+@pytest.mark.parametrize("lat,res,dt,abb", MASKED_TWO_STEP, ids=[f"{t[0]}-{'x'.join(map(str, t[1]))}-{t[2]}-{t[3]}" for t in MASKED_TWO_STEP])
+@pytest.mark.parametrize("coll", ["bgk", "none"])
+@pytest.mark.parametrize("seg", [0, 2, 3])
+def test_masked_two_step_launch_is_bit_identical_to_two_masked_single_steps(lat, res, dt, abb, coll, seg):
+    """lbm2m_kernel: bounce-back, equilibrium (table and per-node field) and an anti-bounce-back outlet at the
+    last plane of the sweep axis (reference layout: logical axis 0, side +1 -- the Obstacle's) with its
+    no-streaming bits: one two-step launch == two one-step launches, bit for bit, for every segment length.
+    Outlets in the other directions are refused (lt_run then keeps the one-step kernel)."""
+    dtype = TORCH_DT[dt]
+    # seg 2: the outlet has the lowest index, so bounce-back / equilibrium nodes ON the outlet plane come after it
+    f0, ncm, nsm, entries = _masked_case(lat, res, dtype, abb, 21, with_field=(seg == 3), abb_first=(seg == 2))
+    plan = plan_for(lat, dtype, coll, res, entries)
+    plan.set_masks(dev(ncm), dev(nsm))
+    f = dev(f0)
+    a, b, c = torch.empty_like(f), torch.empty_like(f), torch.full_like(f, float("nan"))
+    plan.stream_collide(f, a, 0.7)
+    plan.stream_collide(a, b, 0.7)
+    refused = abb is not None and abb != (0, 1)
+    if seg and res[0] % seg:
+        seg = 2 if res[0] % 2 == 0 else 0
+    plan.set_two_step(1, seg)
+    if refused:
+        with pytest.raises(Exception, match="two steps per launch"):
+            plan.stream_collide_twice(f, c, 0.7)
+        return
+    plan.stream_collide_twice(f, c, 0.7)
+    torch.cuda.synchronize()
+    assert "lbm2m_kernel" in plan.kernel_name()
+    np.testing.assert_array_equal(c.cpu().numpy(), b.cpu().numpy())
+
+
+def test_masked_two_step_is_refused_when_no_streaming_bits_lie_off_the_outlet_plane():
+    """The admission test of the masked two-step kernel runs on the device when the masks are compiled."""
+    f0, ncm, nsm, entries = _masked_case("D3Q19", [4, 8, 64], torch.float32, (0, 1), 3)
+    nsm[5, 2, 3, 7] = 1                                    # a stray bit on a fluid node
+    plan = plan_for("D3Q19", torch.float32, "bgk", [4, 8, 64], entries)
+    plan.set_masks(dev(ncm), dev(nsm))
+    plan.set_two_step(1)
+    assert "lbm_kernel" in plan.kernel_name()
+    a, b = dev(f0), torch.empty_like(dev(f0))
+    out, _ = plan.run(a, b, 0.7, 5)                        # lt_run falls back to the one-step kernel
+    assert plan.last_run_info()["two_step_launches"] == 0
+    with pytest.raises(Exception, match="two steps per launch"):
+        plan.stream_collide_twice(a, b, 0.7)
+
+
+MASKED_GOLDEN = [("obstacle3d_d3q19_bgk_12x16x64_f32", "D3Q19", "f32", (1, 2, 3, 8)),
+                 ("obstacle3d_d3q27_bgk_10x8x64_f32", "D3Q27", "f32", (1, 2, 3, 8))]
+
+
+@pytest.mark.parametrize("name,lat,dt,snaps", MASKED_GOLDEN, ids=[t[0] for t in MASKED_GOLDEN])
+def test_masked_two_step_on_obstacle_vectors_of_the_reference(name, lat, dt, snaps):
+    """The reference's Obstacle (inlet + anti-bounce-back outlet along x = the sweep axis + sphere bounce-back)
+    on grids the two-step tiles take: lt_run with pairing == lt_run without, exactly, and both match the
+    reference's populations at the outlet's rounding level."""
+    g = golden(name)
+    plan = obstacle_plan(g, lat, "bgk", dt)
+    for n in snaps:
+        plan.set_two_step(0)
+        single = run_engine(plan, g["f0"], float(g["tau"]), n)
+        plan.set_two_step(1)
+        paired = run_engine(plan, g["f0"], float(g["tau"]), n)
+        info = plan.last_run_info()
+        assert info["two_step_launches"] == (n - 1) // 2, info
+        np.testing.assert_array_equal(paired, single)
+        assert_close(paired, g[f"f{n}"], dt)
+
+
 BIT_IDENTICAL = [t for t in TGV if t[2] == "bgk"]
 
 
