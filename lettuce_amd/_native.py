@@ -208,7 +208,7 @@ class Plan:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self._keepalive = []
+        self._keepalive = {}            # boundary index -> field tensor the engine holds a pointer to
         desc = _PlanDesc()
         desc.abi_version = LT_ABI_VERSION
         desc.stencil = STENCIL_IDS[stencil]
@@ -221,7 +221,7 @@ class Plan:
         for a in range(3):
             desc.shape[a] = self.resolution[a] if a < self.d else 1
         for i, b in enumerate(boundaries):
-            self._fill_boundary(desc.boundaries[i], b)
+            self._fill_boundary(desc.boundaries[i], b, i)
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             self._check(self.lib.lt_plan_create(ctypes.byref(desc), ctypes.byref(handle)))
@@ -229,7 +229,7 @@ class Plan:
         self.n_boundaries = len(boundaries)
 
     # ------------------------------------------------------------------ helpers
-    def _fill_boundary(self, out: _BoundaryDesc, b: dict):
+    def _fill_boundary(self, out: _BoundaryDesc, b: dict, index: int):
         out.kind = BOUNDARY_KINDS[b["kind"]]
         out.axis = int(b.get("axis", 0))
         out.side = int(b.get("side", 0))
@@ -238,9 +238,13 @@ class Plan:
             field = b.get("field")
             if field is not None:
                 field = field.to(device=self.device, dtype=self.dtype).contiguous()
-                self._keepalive.append(field)
+                old = self._keepalive.get(index)
+                if old is not None and old is not field and old.is_cuda:
+                    old.record_stream(torch.cuda.current_stream())   # launches in flight may still read it
+                self._keepalive[index] = field          # a superseded field is released
                 out.feq_field_dev = field.data_ptr()
             else:
+                self._keepalive.pop(index, None)
                 for q, v in enumerate(b["feq"]):
                     out.feq[q] = float(v)
 
@@ -304,7 +308,7 @@ class Plan:
     @_on_device
     def update_boundary(self, index: int, b: dict):
         d = _BoundaryDesc()
-        self._fill_boundary(d, b)
+        self._fill_boundary(d, b, index)
         self._check(self.lib.lt_plan_update_boundary(self._handle, index, ctypes.byref(d),
                                                      _stream_handle()))
 

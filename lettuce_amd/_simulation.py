@@ -40,6 +40,11 @@ class Collision(ABC):
 
 class Reporter(ABC):
     interval: int
+    # The reference calls every reporter after every step (lettuce/_simulation.py:203-205).  The engine
+    # fuses the steps between two calls into one batch only for reporters that declare that they do
+    # nothing unless ``flow.i % interval == 0`` (the library's reporters do); any other Reporter
+    # subclass is called after every single step, exactly as in the reference.
+    batchable: bool = False
 
     def __init__(self, interval: int):
         self.interval = interval
@@ -277,13 +282,15 @@ class Simulation:
     def _steps_to_next_report(self, limit: int) -> int:
         """Reporters are called after every step but library reporters act only when
         ``flow.i % interval == 0`` (lettuce/ext/_reporter/observable_reporter.py:185).  Steps
-        in between can be fused into one engine batch.  A reporter without an integer
-        ``interval`` (or with ``every_step = True``) is honoured after each step."""
+        in between can be fused into one engine batch -- for reporters that opt in with
+        ``batchable = True`` (ObservableReporter, ErrorReporter).  Any other reporter, one without
+        an integer ``interval`` or one with ``every_step = True`` is honoured after each step, and
+        relaxation time and boundary parameters are then re-read every step, as in the reference."""
         k = limit
         for r in self.reporter:
             interval = getattr(r, "interval", None)
-            if (getattr(r, "every_step", False) or not isinstance(interval, (int, np.integer))
-                    or interval < 1):
+            if (not getattr(r, "batchable", False) or getattr(r, "every_step", False)
+                    or not isinstance(interval, (int, np.integer)) or interval < 1):
                 return 1
             k = min(k, interval - self.flow.i % interval)
         return max(1, k)

@@ -42,7 +42,7 @@ import torch.distributed as dist
 
 from .util import LettuceException
 
-__all__ = ["ZSlab", "SlabSimulation", "TwoStepSlabSimulation"]
+__all__ = ["ZSlab", "SlabSimulation", "TwoStepSlabSimulation", "SlabKineticEnergy"]
 
 
 class ZSlab:
@@ -157,6 +157,23 @@ class _PeerWindow:
         return self.local[p, 1], self.local[p, 0]
 
 
+class SlabKineticEnergy:
+    """IncompressibleKineticEnergy of the WHOLE domain for ``ObservableReporter`` on a slab driver: a rank
+    holds only its slab (``flow.f`` is None there), so the library's observables, which read ``flow.f``,
+    cannot be used; this one asks the driver (device reduction on the slab + all-reduce)."""
+    slab_aware = True
+
+    def __init__(self, flow):
+        self.context = flow.context
+        self.flow = flow
+        self.simulation = None              # bound by the slab driver
+
+    def __call__(self, f=None):
+        if self.simulation is None:
+            raise LettuceException("SlabKineticEnergy is evaluated through a slab driver's reporter")
+        return torch.tensor(self.simulation.kinetic_energy_pu(), dtype=torch.float64)
+
+
 class SlabSimulation:
     """Time-step driver of one rank's slab.
 
@@ -176,11 +193,23 @@ class SlabSimulation:
         if list(flow.resolution) != slab.extended_resolution:
             raise LettuceException(f"flow resolution {flow.resolution} != extended slab "
                                    f"{slab.extended_resolution}")
+        if slab.halo < self.GHOST:
+            raise LettuceException(f"ZSlab.halo = {slab.halo} planes, the driver needs {self.GHOST} ghost planes")
         self.flow, self.collision, self.slab = flow, collision, slab
         self.context = flow.context
         self.reporter = reporter if reporter is not None else []
+        for r in self.reporter:
+            # a rank holds its slab only: reporters whose observable reads flow.f cannot work here
+            obs = getattr(r, "observable", None)
+            if not getattr(r, "slab_aware", False) and not getattr(obs, "slab_aware", False):
+                raise LettuceException(
+                    f"reporter {type(r).__name__} reads flow.f, which a slab rank does not hold; use an "
+                    f"observable that asks the driver (e.g. SlabKineticEnergy) or mark the reporter slab_aware")
+            if obs is not None and getattr(obs, "slab_aware", False):
+                obs.simulation = self
         self.group = group
         self.i = 0
+        flow.i = 0
         self.overlap = overlap and self.context.device.type == "cuda"
         nx, ny, _ = slab.global_resolution
         nzl, h, g = slab.nz_local, slab.halo, self.GHOST
@@ -388,7 +417,8 @@ class SlabSimulation:
         k = limit
         for r in self.reporter:
             interval = getattr(r, "interval", None)
-            if not isinstance(interval, (int, np.integer)) or interval < 1:
+            if (not getattr(r, "batchable", False) or not isinstance(interval, (int, np.integer))
+                    or interval < 1):
                 return 1
             k = min(k, interval - self.i % interval)
         return max(1, k)
@@ -404,6 +434,7 @@ class SlabSimulation:
             k = self._next_report(remaining)
             self._advance(k)
             self.i += k
+            self.flow.i = self.i            # reporters read simulation.flow.i
             remaining -= k
             for r in self.reporter:
                 r(self)
@@ -411,6 +442,10 @@ class SlabSimulation:
             torch.cuda.synchronize(self.context.device)
         nx, ny, _ = self.slab.global_resolution
         return num_steps * nx * ny * self.nzl / 1e6 / (timer() - beg)
+
+    @property
+    def units(self):
+        return self.flow.units
 
     # ---- observables -----------------------------------------------------------------------------
     def kinetic_energy_pu(self) -> float:

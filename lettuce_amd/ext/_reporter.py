@@ -101,6 +101,7 @@ class Mass(Observable):
 class ObservableReporter(Reporter):
     """Evaluates ``observable`` every ``interval`` steps and prints ``i t_pu value...`` or
     appends it to ``out`` when that is a list (observable_reporter.py:161-199)."""
+    batchable = True          # does nothing unless flow.i % interval == 0: steps in between may be fused
 
     def __init__(self, observable, interval=1, out=sys.stdout):
         super().__init__(interval)
@@ -126,6 +127,7 @@ class ErrorReporter(Reporter):
     """L2 errors of u and p (physical units) against an analytic solution, e.g.
     ``flow.analytic_solution`` of the 2-D Taylor-Green vortex; used by the convergence check
     ("next" row F4; lettuce/ext/_reporter/error_reporter.py:9-48, lettuce/cli.py:128-180)."""
+    batchable = True
 
     def __init__(self, analytical_solution, interval=1, out=sys.stdout):
         Reporter.__init__(self, interval)

@@ -223,6 +223,8 @@ def test_reporter_cadence_and_deprecated_step():
     assert rep.i == [0, 1, 2, 3, 4, 5]
     assert sim._steps_to_next_report(100) == 1
     rep.interval = 4
+    assert sim._steps_to_next_report(100) == 1        # an unknown Reporter subclass is called after every step
+    rep.batchable = True                              # ... unless it declares that it only acts on its interval
     assert sim._steps_to_next_report(100) == 3        # i = 5 -> next multiple of 4 is 8
     sim.reporter.clear()
     assert sim._steps_to_next_report(100) == 100
@@ -349,3 +351,24 @@ def test_bench_finds_the_committed_pmc_traffic_for_the_fused_kernel(monkeypatch)
     # names that gained trailing template parameters since the profile was taken still match
     assert bench.traffic_from_profile(name.replace(", 1>", ", 1, 0>")) == traffic
     assert bench.traffic_from_profile("lbm_kernel<float, lt::d3q19, 0, 1, true, true, false, 1, 0, 0, false>") is None
+
+
+def test_only_reporters_that_opt_in_are_batched():
+    """The reference calls every reporter after every step (lettuce/_simulation.py:203-205); the engine fuses
+    the steps between two calls only for reporters that declare batchable = True (the library's do)."""
+    flow = lt.TaylorGreenVortex(ctx(), [8, 8], 100, 0.05, lt.D2Q9())
+    calls = []
+
+    class EveryStep(lt.Reporter):
+        def __call__(self, simulation):
+            calls.append(simulation.flow.i)
+
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setattr("sys.stdout", io.StringIO())
+        lib = lt.ObservableReporter(lt.IncompressibleKineticEnergy(flow), interval=5, out=[])
+    sim = lt.Simulation(flow, lt.BGKCollision(0.6), [lib])
+    assert sim._steps_to_next_report(100) == 5
+    sim.reporter = [lib, EveryStep(interval=5)]          # an unknown subclass: no batching, whatever its interval
+    assert sim._steps_to_next_report(100) == 1
+    EveryStep.batchable = True
+    assert sim._steps_to_next_report(100) == 5

@@ -154,3 +154,67 @@ def test_slab_ranks_with_obstacle_boundaries(tmp_path, world):
     g, got = golden(name), np.load(tmp_path / "out.npz")
     np.testing.assert_allclose(got["f0"], g["f0"], rtol=0, atol=1e-15)
     np.testing.assert_allclose(got["f1"], g["f8"], rtol=0, atol=1e-12)
+
+
+def _reporter_worker(rank, world, port, res, steps, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import io
+    import contextlib
+    import lettuce_amd as lt
+    from slab_cpu_engine import OracleSlabEngine
+    ctx = lt.Context("cpu", torch.float64, use_native=False)
+    slab = lt.ZSlab(res)
+    flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 400, 0.1, lt.D3Q19(), slab=slab)
+    out = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        rep = lt.ObservableReporter(lt.SlabKineticEnergy(flow), interval=3, out=out)
+        bad = lt.ObservableReporter(lt.IncompressibleKineticEnergy(flow), interval=3, out=[])
+    coll = lt.BGKCollision(flow.units.relaxation_parameter_lu)
+    refused = False
+    try:
+        lt.SlabSimulation(flow, coll, slab, reporter=[bad], engine=OracleSlabEngine("D3Q19", torch.float64, "bgk"))
+    except lt.LettuceException:
+        refused = True
+    flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 400, 0.1, lt.D3Q19(), slab=slab)
+    sim = lt.SlabSimulation(flow, coll, slab, reporter=[rep], engine=OracleSlabEngine("D3Q19", torch.float64, "bgk"))
+    sim(steps)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "out.npz"), series=np.array(out, dtype=np.float64), refused=refused,
+                 flow_i=flow.i)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slab_driver_with_an_observable_reporter(tmp_path):
+    """Reporters on slabs: flow.i follows the driver, an ObservableReporter around the
+    slab-aware kinetic energy logs the all-reduced series of the whole domain, and a reporter whose
+    observable reads flow.f is refused with a LettuceException instead of failing on flow.f = None."""
+    from oracle import lettuce_oracle as orc
+    res, steps = [8, 6, 8], 7
+    mp.spawn(_reporter_worker, args=(2, 29700 + os.getpid() % 2000, res, steps, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "out.npz")
+    assert bool(got["refused"]) and int(got["flow_i"]) == steps
+    ref = orc.taylor_green(res, 400, 0.1, "D3Q19", torch.float64)
+    want = {0: float(orc.kinetic_energy_pu(ref.f, ref.lat, ref.units))}
+    for i in range(1, steps + 1):
+        ref.step(1)
+        if i % 3 == 0:
+            want[i] = float(orc.kinetic_energy_pu(ref.f, ref.lat, ref.units))
+    series = got["series"]
+    assert [int(r[0]) for r in series] == sorted(want)
+    for row in series:
+        assert row[2] == pytest.approx(want[int(row[0])], rel=1e-12)
+        assert row[1] == pytest.approx(ref.units.time_to_pu(int(row[0])), rel=1e-12)
+
+
+def test_slab_halo_narrower_than_the_ghost_planes_is_refused():
+    import lettuce_amd as lt
+    from slab_cpu_engine import OracleSlabEngine
+    ctx = lt.Context("cpu", torch.float64, use_native=False)
+    slab = lt.ZSlab([6, 4, 8], rank=0, world_size=1, halo=1)
+    flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 100, 0.1, lt.D3Q19(), slab=slab, initialize_fneq=False)
+    with pytest.raises(lt.LettuceException, match="ghost planes"):
+        lt.TwoStepSlabSimulation(flow, lt.BGKCollision(0.6), slab, engine=OracleSlabEngine("D3Q19", torch.float64, "bgk"))
