@@ -179,8 +179,9 @@ class SlabSimulation:
 
     ``flow`` is built on ``slab.extended_resolution`` with ``slab=slab`` (so that its initial
     condition and its boundary masks equal the global ones on this rank's planes); ``collision``
-    is a BGK / KBC / NoCollision object.  Boundaries may be bounce-back, uniform equilibrium and
-    an anti-bounce-back outlet along x or y (not along the decomposed z axis).  ``engine`` defaults to the HIP engine; tests inject a
+    is a BGK / KBC / NoCollision object.  Boundaries may be bounce-back, equilibrium (uniform or with
+    per-node velocity / pressure given on the extended slab) and an anti-bounce-back outlet along x or y
+    (not along the decomposed z axis).  ``engine`` defaults to the HIP engine; tests inject a
     CPU stand-in with the same three ``*_planes`` methods to exercise the decomposition and the
     exchange with the gloo backend.
     """
@@ -229,8 +230,10 @@ class SlabSimulation:
                 raise LettuceException(f"boundary '{type(b).__name__}' has no engine kernel")
             entry = b.native_generator(i).plan_entry(flow)
             if "field" in entry:
-                raise LettuceException("per-node equilibrium-boundary arguments are not supported "
-                                       "by the slab driver (use uniform velocity / pressure)")
+                # per-node boundary arguments (equilibrium_boundary_pu.py:21-40) were given on the extended
+                # slab like everything else of the flow: cut this rank's planes + ghost planes, z slowest
+                entry = dict(entry)
+                entry["field"] = entry["field"][..., h - g:h + nzl + g].permute(0, 3, 2, 1).contiguous()
             entries.append(entry)
         if ncm is not None:
             ncm = ncm[..., h - g:h + nzl + g].permute(2, 1, 0).contiguous()

@@ -18,12 +18,14 @@ class OracleSlabEngine:
         [q, nz+2, ny, nx]."""
         self.entries, self.ncm, self.nsm = entries, ncm, nsm
 
-    def _boundaries(self, g, ncm):
-        """g: [q, x, y, zsub] (reference axis order), ncm: [x, y, zsub]; boundaries in index
-        order, each seeing the current field (lettuce/_simulation.py:186-188)."""
+    def _boundaries(self, g, ncm, lo, hi):
+        """g: [q, x, y, zsub] (reference axis order), ncm: [x, y, zsub], planes [lo, hi) of the slab;
+        boundaries in index order, each seeing the current field (lettuce/_simulation.py:186-188)."""
         for idx, b in enumerate(self.entries, start=1):
             if b["kind"] == "bounce_back":
                 new = orc.bounce_back(g, self.lat)
+            elif b["kind"] == "equilibrium" and "field" in b:
+                new = b["field"][:, lo:hi].permute(0, 3, 2, 1).to(g.dtype)     # [q, z, y, x] -> [q, x, y, zsub]
             elif b["kind"] == "equilibrium":
                 feq = torch.tensor(b["feq"], dtype=g.dtype).reshape(-1, 1, 1, 1)
                 new = feq * torch.ones_like(g)
@@ -58,7 +60,7 @@ class OracleSlabEngine:
         g = planes.permute(0, 3, 2, 1).clone()                  # [q, x, y, zsub]
         ncm = self.ncm[b:e].permute(2, 1, 0)
         g = torch.where(ncm == 0, self._collide(g, tau), g)
-        return self._boundaries(g, ncm).permute(0, 3, 2, 1)
+        return self._boundaries(g, ncm, b, e).permute(0, 3, 2, 1)
 
     def _stream(self, f, b, e):
         pulled = self._pull(f, b, e)

@@ -271,6 +271,40 @@ def test_slab_driver_single_rank_on_gpu():
         np.testing.assert_allclose(sim.gather_f().cpu().numpy(), ref.f.numpy(), rtol=0, atol=2e-6)
 
 
+def test_slab_driver_with_per_node_equilibrium_boundary_on_gpu():
+    """Per-node inlet fields on the slab-layout kernels (one rank): SlabSimulation == Simulation on the whole
+    grid with the same EquilibriumBoundaryPU(velocity field, pressure field)."""
+    res, steps = [16, 8, 12], 6
+
+    def setup(c, slab=None):
+        torch.manual_seed(17)
+        vel = 0.05 * torch.rand([3] + res, dtype=torch.float64)
+        prs = 0.01 * torch.rand(res, dtype=torch.float64)
+        mask = torch.zeros(res, dtype=torch.bool)
+        mask[2:5, 1:4, :] = True
+        if slab is not None:
+            z = slab.z_indices()
+            vel, prs, mask = vel[..., z], prs[..., z], mask[..., z]
+
+        class Forced(lt.TaylorGreenVortex):
+            extra = None
+
+            @property
+            def boundaries(self):
+                return [] if self.extra is None else [self.extra]
+        flow = Forced(c, slab.extended_resolution if slab is not None else res, 400, 0.1, lt.D3Q19(), slab=slab)
+        flow.extra = lt.EquilibriumBoundaryPU(c, mask.cuda(), vel, prs)
+        return flow
+    c = gpu("f64")
+    whole = setup(c)
+    lt.Simulation(whole, lt.BGKCollision(whole.units.relaxation_parameter_lu), [])(steps)
+    slab = lt.ZSlab(res, rank=0, world_size=1)
+    part = setup(c, slab)
+    sim = lt.SlabSimulation(part, lt.BGKCollision(part.units.relaxation_parameter_lu), slab)
+    sim(steps)
+    np.testing.assert_allclose(sim.gather_f().cpu().numpy(), whole.f.cpu().numpy(), rtol=0, atol=1e-14)
+
+
 def test_cfg1_simplest_tgv_energy_anchors():
     """BASELINE configs[0] = examples/00_simplest_TGV.py (D2Q9 128^2 fp64 Re 100 Ma 0.05, BGK,
     1000 steps) on the HIP engine against the reference CPU path: populations after 100 steps
