@@ -17,6 +17,7 @@ def timed(sim, warm, steps):
         info["single_step_launches"] or 8 * info["many_step_launches"])
     fused_ms = e0.elapsed_time(e1) / max(1, updates)
     sim._native.fused_events = None
+    timed.updates_per_launch = 2 if info["two_step_launches"] else (8 if info["many_step_launches"] else 1)
     return dt, fused_ms
 
 def residency_ab(sim, steps=40):
@@ -34,11 +35,14 @@ def residency_ab(sim, steps=40):
 def report(name, flow, sim, dt, fused_ms, steps, bytes_per_node):
     n = 1
     for r in flow.resolution: n *= r
-    gbs = bytes_per_node * n / (fused_ms * 1e-3) / 1e9
+    gbs = bytes_per_node * n / (fused_ms * 1e-3) / 1e9           # algorithmic bytes of lattice updates per second
+    upl = getattr(timed, "updates_per_launch", 1)
+    hbm = gbs / upl                                               # populations read once + written once per launch
     print(json.dumps({"config": name, "resolution": flow.resolution, "steps": steps,
-                      "mlups_wall": round(steps * n / dt / 1e6, 1), "fused_kernel_ms": round(fused_ms, 5),
-                      "fused_GBps": round(gbs, 1), "frac_of_8TBs": round(gbs / 8000, 4),
-                      "bytes_per_node": bytes_per_node, "kernel": sim._native.plan.kernel_name()}), flush=True)
+                      "mlups_wall": round(steps * n / dt / 1e6, 1), "ms_per_update": round(fused_ms, 5),
+                      "updates_per_launch": upl, "hbm_GBps_required": round(hbm, 1),
+                      "frac_of_8TBs": round(hbm / 8000, 4), "algorithmic_update_GBps": round(gbs, 1),
+                      "bytes_per_node_and_update": bytes_per_node, "kernel": sim._native.plan.kernel_name()}), flush=True)
 
 def main():
     which = sys.argv[1:] or ["cfg1", "cfg4", "cfg5", "cfg4bgk"]
