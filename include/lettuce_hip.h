@@ -66,6 +66,7 @@ enum lt_boundary_kind {
   LT_BOUNDARY_ABB_OUTLET = 3
 };
 enum lt_layout { LT_LAYOUT_REFERENCE = 0, LT_LAYOUT_SLAB = 1 };
+#define LT_BOUNDARY_ABSENT 1
 
 /* One entry of Simulation.boundaries[1:] (lettuce/_simulation.py:57-58); entry i (0-based)
  * is the boundary whose index in no_collision_mask is i + 1. */
@@ -73,7 +74,9 @@ typedef struct lt_boundary_desc {
   int32_t kind;            /* lt_boundary_kind */
   int32_t axis;            /* ABB outlet: logical axis of `direction` (0 = x) */
   int32_t side;            /* ABB outlet: +1 or -1 */
-  int32_t reserved;
+  int32_t flags;           /* ABB outlet on a slab plan (ghost_planes > 0) whose normal is the decomposed axis:
+                            * bit 0 (LT_BOUNDARY_ABSENT) = another rank holds the first / last plane of the
+                            * global grid, this rank has no outlet; else 0 */
   /* EQUILIBRIUM with uniform velocity/pressure: the populations written on the masked
    * nodes, i.e. feq(rho(p_pu), u_lu(v_pu)) as the host evaluated it in the flow's dtype. */
   double feq[LT_MAX_Q];

@@ -42,7 +42,7 @@ class NativeEngineError(LettuceException):
 
 class _BoundaryDesc(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("axis", ctypes.c_int32), ("side", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("feq", ctypes.c_double * LT_MAX_Q),
+                ("flags", ctypes.c_int32), ("feq", ctypes.c_double * LT_MAX_Q),
                 ("feq_field_dev", ctypes.c_void_p)]
 
 
@@ -233,6 +233,7 @@ class Plan:
         out.kind = BOUNDARY_KINDS[b["kind"]]
         out.axis = int(b.get("axis", 0))
         out.side = int(b.get("side", 0))
+        out.flags = 0 if b.get("present", True) else 1      # LT_BOUNDARY_ABSENT: another rank holds the outlet plane
         out.feq_field_dev = None
         if b["kind"] == "equilibrium":
             field = b.get("field")

@@ -180,8 +180,9 @@ class SlabSimulation:
     ``flow`` is built on ``slab.extended_resolution`` with ``slab=slab`` (so that its initial
     condition and its boundary masks equal the global ones on this rank's planes); ``collision``
     is a BGK / KBC / NoCollision object.  Boundaries may be bounce-back, equilibrium (uniform or with
-    per-node velocity / pressure given on the extended slab) and an anti-bounce-back outlet along x or y
-    (not along the decomposed z axis).  ``engine`` defaults to the HIP engine; tests inject a
+    per-node velocity / pressure given on the extended slab) and an anti-bounce-back outlet along any axis
+    (along z it lives on the rank that holds the first / last plane of the global grid, together with the
+    plane next to it).  ``engine`` defaults to the HIP engine; tests inject a
     CPU stand-in with the same three ``*_planes`` methods to exercise the decomposition and the
     exchange with the gloo backend.
     """
@@ -247,6 +248,8 @@ class SlabSimulation:
             if ncm is not None:
                 engine.set_masks(ncm, nsm)
         elif entries:
+            if hasattr(engine, "ghosts"):
+                engine.ghosts = g
             engine.set_boundaries(entries, ncm, nsm, flow.units)      # test stand-ins
         self.engine = engine
         # [q, nx, ny, nzl + 2g] incl. the ghost planes -> [q, nzl + 2g, ny, nx]

@@ -127,8 +127,12 @@ int upload_boundaries(lt_plan *p, hipStream_t stream) {
       const int ax = mem_axis_of(p, b.axis);
       h.mem_axis[s] = ax;
       h.side[s] = b.side;
-      h.plane[s] = b.side > 0 ? ext[ax] - 1 : 0;
-      h.nbr[s] = b.side > 0 ? ext[ax] - 2 : 1;
+      // along the decomposed axis of a slab the first / last plane of the grid is the first / last
+      // interior plane of the rank that holds it; the other ranks have no outlet (a plane no node has)
+      const int g = ax == 2 ? p->desc.ghost_planes : 0;
+      h.plane[s] = b.side > 0 ? ext[ax] - 1 - g : g;
+      h.nbr[s] = h.plane[s] - b.side;
+      if (g && (b.flags & LT_BOUNDARY_ABSENT)) h.plane[s] = h.nbr[s] = -1000000;
     } else if (b.kind == LT_BOUNDARY_EQUILIBRIUM) {
       for (int q = 0; q < p->unit.q; ++q) h.feq[s][q] = (T)b.feq[q];
       h.field[s] = static_cast<const T *>(b.feq_field_dev);
@@ -150,8 +154,8 @@ int check_boundary(const lt_plan *p, const lt_boundary_desc &b, int n_abb_before
         return fail(LT_ERR_INVALID, "anti-bounce-back outlet: axis %d side %d", b.axis, b.side);
       if (p->desc.shape[b.axis] < 2)
         return fail(LT_ERR_INVALID, "anti-bounce-back outlet needs >= 2 planes along its axis");
-      if (p->desc.ghost_planes && b.axis == 2)
-        return fail(LT_ERR_UNSUPPORTED, "an outlet along the decomposed (z) axis of a slab");
+      if (p->desc.ghost_planes && b.axis == 2 && !(b.flags & LT_BOUNDARY_ABSENT) && p->desc.shape[2] < 2)
+        return fail(LT_ERR_INVALID, "an outlet along the decomposed (z) axis needs >= 2 planes on its rank");
       if (n_abb_before > 0)
         return fail(LT_ERR_UNSUPPORTED,
                     "more than one AntiBounceBackOutlet per flow is not supported by the HIP engine");

@@ -11,6 +11,8 @@ from typing import List, Optional
 import numpy as np
 import torch
 
+from ..util import LettuceException
+
 from .._flow import Boundary
 from ..native_desc import NativeBoundary
 from ._collision import BGKCollision
@@ -113,6 +115,19 @@ class AntiBounceBackOutlet(Boundary):
         self.neighbor = [slice(None)] * len(direction)
         self.index[self.axis] = -1 if self.side > 0 else 0
         self.neighbor[self.axis] = -2 if self.side > 0 else 1
+        # z-slab decomposition (multi-GPU extension, lettuce_amd/_slab.py): an outlet along the decomposed
+        # axis lives on the rank that holds the first / last plane of the GLOBAL grid; `flow` is that
+        # rank's extended slab, so the plane's index is shifted, and the other ranks have no outlet
+        self.present = True
+        slab = getattr(flow, "slab", None)
+        if slab is not None and self.axis == 2:
+            plane = (slab.global_resolution[2] - 1 if self.side > 0 else 0) - slab.z_begin
+            self.present = 0 <= plane < slab.nz_local
+            if self.present and not 0 <= plane - self.side < slab.nz_local:
+                raise LettuceException("an outlet along z needs its plane and the plane next to it on one rank "
+                                       "(at least two planes per rank)")
+            self.index[2] = slab.halo + plane
+            self.neighbor[2] = slab.halo + plane - self.side
         w = flow.torch_stencil.w[self.velocities]
         self.w = w.reshape([-1] + [1] * (len(direction) - 1))
 
@@ -120,6 +135,8 @@ class AntiBounceBackOutlet(Boundary):
         return context.convert_to_ndarray(self.stencil.opposite)[self.velocities]
 
     def __call__(self, flow: "Flow"):
+        if not self.present:
+            return flow.f
         st = flow.torch_stencil
         u = flow.u()
         here = tuple([slice(None)] + self.index)
@@ -138,12 +155,14 @@ class AntiBounceBackOutlet(Boundary):
 
     def make_no_streaming_mask(self, f_shape, context: "Context"):
         mask = torch.zeros(size=list(f_shape), dtype=torch.bool, device=context.device)
-        mask[tuple([self._opposite_of_velocities(context)] + self.index)] = 1
+        if self.present:
+            mask[tuple([self._opposite_of_velocities(context)] + self.index)] = 1
         return mask
 
     def make_no_collision_mask(self, shape: List[int], context: "Context"):
         mask = context.zero_tensor(shape, dtype=bool)
-        mask[tuple(self.index)] = 1
+        if self.present:
+            mask[tuple(self.index)] = 1
         return mask
 
     def native_available(self) -> bool:
@@ -151,4 +170,4 @@ class AntiBounceBackOutlet(Boundary):
 
     def native_generator(self, index: int) -> "NativeBoundary":
         return NativeBoundary("abb_outlet", index,
-                              params=lambda flow: {"axis": self.axis, "side": self.side})
+                              params=lambda flow: {"axis": self.axis, "side": self.side, "present": self.present})

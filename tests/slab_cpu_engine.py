@@ -12,6 +12,7 @@ class OracleSlabEngine:
         self.e, self.w = orc.lattice_tensors(self.lat, dtype)
         self.collision = collision
         self.entries, self.ncm, self.nsm = [], None, None
+        self.ghosts = 1                   # ghost planes per side of the slab tensors (set by the driver's GHOST)
 
     def set_boundaries(self, entries, ncm, nsm, units):
         """entries as for lettuce_amd._native.Plan; masks in slab layout [nz+2, ny, nx] /
@@ -29,6 +30,26 @@ class OracleSlabEngine:
             elif b["kind"] == "equilibrium":
                 feq = torch.tensor(b["feq"], dtype=g.dtype).reshape(-1, 1, 1, 1)
                 new = feq * torch.ones_like(g)
+            elif b["axis"] == 2:
+                # outlet along the decomposed axis: on the rank that holds it, the plane and its neighbour are
+                # the last / first two interior planes of the slab; the block [lo, hi) was extended to hold both
+                if not b.get("present", True):
+                    continue
+                n2 = self.ncm.shape[0]
+                ghosts = self.ghosts
+                plane = n2 - 1 - ghosts if b["side"] > 0 else ghosts
+                nbr = plane - b["side"]
+                if not (lo <= plane < hi):
+                    continue
+                assert lo <= nbr < hi
+                pair = g[..., [nbr - lo, plane - lo]] if b["side"] > 0 else g[..., [plane - lo, nbr - lo]]
+                direction = [0, 0, b["side"]]
+                pair = orc.abb_outlet_inplace(pair.clone(), orc.OracleBoundary("abb_outlet", direction=direction),
+                                              self.lat, self.e, self.w)
+                new = g.clone()
+                new[..., plane - lo] = pair[..., -1 if b["side"] > 0 else 0]
+                g = new              # the outlet rewrites its whole plane, whatever the nodes' indices
+                continue
             else:
                 direction = [0, 0, 0]
                 direction[b["axis"]] = b["side"]
@@ -36,6 +57,17 @@ class OracleSlabEngine:
                                              self.lat, self.e, self.w)
             g = torch.where(ncm == idx, new, g)
         return g
+
+    def _z_outlet_range(self, b0, e0):
+        """[lo, hi) >= [b0, e0) that also holds the plane next to a z outlet inside [b0, e0)"""
+        lo, hi = b0, e0
+        for b in self.entries:
+            if b["kind"] == "abb_outlet" and b["axis"] == 2 and b.get("present", True):
+                n2 = self.ncm.shape[0]
+                plane = n2 - 1 - self.ghosts if b["side"] > 0 else self.ghosts
+                if b0 <= plane < e0:
+                    lo, hi = min(lo, plane - b["side"]), max(hi, plane - b["side"] + 1)
+        return lo, hi
 
     def _collide(self, f, tau):
         if self.collision == "bgk":
@@ -69,13 +101,15 @@ class OracleSlabEngine:
         return torch.where(self.nsm[:, b:e] == 1, f[:, b:e], pulled)
 
     def collide_planes(self, f, out, tau, b, e):
-        out[:, b:e] = self._collide_and_boundaries(f[:, b:e], tau, b, e)
+        lo, hi = self._z_outlet_range(b, e) if self.ncm is not None else (b, e)
+        out[:, b:e] = self._collide_and_boundaries(f[:, lo:hi], tau, lo, hi)[:, b - lo:e - lo]
 
     def stream_planes(self, f, out, b, e):
         out[:, b:e] = self._stream(f, b, e)
 
     def stream_collide_planes(self, f, out, tau, b, e):
-        out[:, b:e] = self._collide_and_boundaries(self._stream(f, b, e), tau, b, e)
+        lo, hi = self._z_outlet_range(b, e) if self.ncm is not None else (b, e)
+        out[:, b:e] = self._collide_and_boundaries(self._stream(f, lo, hi), tau, lo, hi)[:, b - lo:e - lo]
 
     # ---- two-step slabs (two ghost planes per side) -------------------------------------------
     def stream_collide_twice_planes(self, f, out, tau, b, e):

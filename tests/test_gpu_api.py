@@ -305,6 +305,37 @@ def test_slab_driver_with_per_node_equilibrium_boundary_on_gpu():
     np.testing.assert_allclose(sim.gather_f().cpu().numpy(), whole.f.cpu().numpy(), rtol=0, atol=1e-14)
 
 
+def test_slab_driver_with_an_outlet_along_z_on_gpu():
+    """An anti-bounce-back outlet along the decomposed axis through the slab-layout kernels (one rank holds the
+    whole grid, so it holds the outlet): == the reference path (non-native mirror on the CPU) of the same flow."""
+    res, steps = [8, 6, 12], 6
+
+    def channel(c, slab=None):
+        zsel = slab.z_indices() if slab is not None else torch.arange(res[2])
+        gz = zsel.reshape(1, 1, -1).expand(res[0], res[1], -1)
+        block = torch.zeros(res, dtype=torch.bool)
+        block[2:4, 1:3, 4:7] = True
+        if slab is not None:
+            block = block[..., zsel]
+
+        class Channel(lt.TaylorGreenVortex):
+            @property
+            def boundaries(self):
+                return [lt.EquilibriumBoundaryPU(self.context, (gz == 0).to(self.context.device), [0.0, 0.0, 0.05]),
+                        lt.AntiBounceBackOutlet([0, 0, 1], self), lt.BounceBackBoundary(block.to(self.context.device))]
+        return Channel(c, slab.extended_resolution if slab is not None else res, 100, 0.05, lt.D3Q19(), slab=slab)
+    want = channel(lt.Context("cpu", torch.float64, use_native=False))
+    lt.Simulation(want, lt.BGKCollision(want.units.relaxation_parameter_lu), [])(steps)
+    slab = lt.ZSlab(res, rank=0, world_size=1)
+    part = channel(gpu("f64"), slab)
+    sim = lt.SlabSimulation(part, lt.BGKCollision(part.units.relaxation_parameter_lu), slab)
+    sim(steps)
+    np.testing.assert_allclose(sim.gather_f().cpu().numpy(), want.f.numpy(), rtol=0, atol=1e-13)
+    whole = channel(gpu("f64"))
+    lt.Simulation(whole, lt.BGKCollision(whole.units.relaxation_parameter_lu), [])(steps)
+    np.testing.assert_allclose(whole.f.cpu().numpy(), want.f.numpy(), rtol=0, atol=1e-13)
+
+
 def test_cfg1_simplest_tgv_energy_anchors():
     """BASELINE configs[0] = examples/00_simplest_TGV.py (D2Q9 128^2 fp64 Re 100 Ma 0.05, BGK,
     1000 steps) on the HIP engine against the reference CPU path: populations after 100 steps

@@ -277,3 +277,56 @@ def test_slab_ranks_with_per_node_equilibrium_boundary_arguments(tmp_path, world
     flow = _field_inlet_setup(lt, ctx, res)
     lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])(steps)
     np.testing.assert_allclose(got["f1"], flow.f.numpy(), rtol=0, atol=1e-13)
+
+
+def _z_channel(lt, ctx, res, slab=None):
+    """Flow along +z: equilibrium inlet on the plane z = 0, anti-bounce-back outlet on z = nz - 1, a
+    bounce-back block in between; on the whole grid or on a rank's extended slab."""
+    zsel = slab.z_indices() if slab is not None else torch.arange(res[2])
+    gz = zsel.reshape(1, 1, -1).expand(res[0], res[1], -1)
+    block = torch.zeros(res, dtype=torch.bool)
+    block[2:4, 1:3, 4:7] = True
+    if slab is not None:
+        block = block[..., zsel]
+
+    class Channel(lt.TaylorGreenVortex):
+        @property
+        def boundaries(self):
+            return [lt.EquilibriumBoundaryPU(self.context, gz == 0, [0.0, 0.0, 0.05]),
+                    lt.AntiBounceBackOutlet([0, 0, 1], self), lt.BounceBackBoundary(block)]
+    return Channel(ctx, slab.extended_resolution if slab is not None else res, 100, 0.05, lt.D3Q19(), slab=slab)
+
+
+def _z_channel_worker(rank, world, port, res, steps, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lettuce_amd as lt
+    from slab_cpu_engine import OracleSlabEngine
+    ctx = lt.Context("cpu", torch.float64, use_native=False)
+    slab = lt.ZSlab(res)
+    flow = _z_channel(lt, ctx, res, slab)
+    sim = lt.SlabSimulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
+                            engine=OracleSlabEngine("D3Q19", torch.float64, "bgk"))
+    sim(steps)
+    f1 = sim.gather_f()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "out.npz"), f1=f1.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_slab_ranks_with_an_outlet_along_the_decomposed_axis(tmp_path, world):
+    """An anti-bounce-back outlet along z on z-slabs: only the rank that holds the last
+    plane of the global grid has the outlet; the result equals the single-domain run."""
+    import lettuce_amd as lt
+    res, steps = [6, 5, 12], 6
+    mp.spawn(_z_channel_worker, args=(world, 29900 + os.getpid() % 2000 + world, res, steps, str(tmp_path)),
+             nprocs=world, join=True)
+    got = np.load(tmp_path / "out.npz")
+    ctx = lt.Context("cpu", torch.float64, use_native=False)
+    flow = _z_channel(lt, ctx, res)
+    lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])(steps)
+    np.testing.assert_allclose(got["f1"], flow.f.numpy(), rtol=0, atol=1e-13)
