@@ -459,14 +459,17 @@ def main():
                             f"kernel ({sim2._native.plan.kernel_name()}), torch.equal on all populations")
             del flow2, sim2, final, pre_timed
     elif distributed:
-        # per-rank fused-kernel rate is not separable from the exchange here; report the
-        # effective whole-step rate of one rank against the same algorithmic bytes
+        # per-rank fused-kernel rate is not separable from the exchange here: the whole-step rate of one rank.
+        # achieved = bytes HBM has to carry (populations read once + written once per LAUNCH; the two-step
+        # driver does two lattice updates per launch) / time, a physical rate like the N = 1 line's
         eff = BYTES_PER_NODE * nodes_per_rank * args.steps / elapsed / 1e9
-        roofline = {"bound": "hbm", "achieved": round(eff, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(eff / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
-                    "note": "whole-step effective rate per GPU in algorithmic bytes (152 B per node and update; "
-                            "includes halo exchange and the collide/stream passes of the batch); with the two-step "
-                            "driver HBM carries about half of it"}
+        per_launch = 2 if driver == "two-step" else 1
+        roofline = {"bound": "hbm", "achieved": round(eff / per_launch, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(eff / per_launch / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
+                    "lattice_updates_per_node_per_launch": per_launch, "algorithmic_update_GBps": round(eff, 1),
+                    "note": "whole-step rate per GPU (includes halo exchange and the collide/stream passes of the "
+                            "batch): populations read once + written once per launch / time; "
+                            "algorithmic_update_GBps counts 152 B per node and update"}
 
     passes = "1 collide + (K-1) fused stream-collide + 1 stream"
     if roofline and roofline.get("lattice_updates_per_node_per_launch", 0) == 2:
