@@ -94,6 +94,7 @@ struct lt_plan {
   void *bt = nullptr;        // BoundaryTable<T>
   double *partial = nullptr;
   int masked = 0;
+  int n_abb = 0;             // anti-bounce-back outlets of the plan
   int nsm_confined = 1;      // every no-streaming bit lies on the anti-bounce-back outlet's plane (lt_plan_set_masks)
   unsigned *mask_flag = nullptr;   // device word written by the mask compilation
   char kernel_name[192];
@@ -156,9 +157,9 @@ int check_boundary(const lt_plan *p, const lt_boundary_desc &b, int n_abb_before
         return fail(LT_ERR_INVALID, "anti-bounce-back outlet needs >= 2 planes along its axis");
       if (p->desc.ghost_planes && b.axis == 2 && !(b.flags & LT_BOUNDARY_ABSENT) && p->desc.shape[2] < 2)
         return fail(LT_ERR_INVALID, "an outlet along the decomposed (z) axis needs >= 2 planes on its rank");
-      if (n_abb_before > 0)
+      if (n_abb_before > 1)
         return fail(LT_ERR_UNSUPPORTED,
-                    "more than one AntiBounceBackOutlet per flow is not supported by the HIP engine");
+                    "more than two AntiBounceBackOutlets per flow are not supported by the HIP engine");
       return LT_OK;
     }
     default:
@@ -366,6 +367,7 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.node = p->node; a.nsm_bits = p->nsm_bits; a.bt = p->bt; a.nb = p->desc.n_boundaries;
   a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = mode;
   a.masked = p->masked;
+  a.abb_depth = p->n_abb > 1 ? p->n_abb - 1 : 0;
   const bool aligned = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
   const bool hot = mode == lt::kFused && !a.masked && a.coll == LT_COLLISION_BGK;
   a.wide = (p->want_wide && hot && p->wide_ok && aligned) ? 1 : 0;
@@ -633,6 +635,7 @@ int lt_plan_create(const lt_plan_desc *d, lt_plan **out) {
     if (rc) { delete p; return rc; }
     if (d->boundaries[i].kind == LT_BOUNDARY_ABB_OUTLET) ++n_abb;
   }
+  p->n_abb = n_abb;
   const size_t bt_size = d->dtype == LT_F32 ? sizeof(lt::BoundaryTable<float>)
                                             : sizeof(lt::BoundaryTable<double>);
   if (hipMalloc(&p->bt, bt_size) != hipSuccess ||
@@ -817,6 +820,7 @@ const char *lt_plan_kernel_name(lt_plan *p) {
   a.mode = (two_step_wanted(p) || p->desc.ghost_planes == 2) ? lt::kFusedTwice : lt::kFused;
   if (many_step_wanted(p)) a.mode = lt::kFusedMany;
   a.masked = p->masked;
+  a.abb_depth = p->n_abb > 1 ? p->n_abb - 1 : 0;
   if (a.mode == lt::kFusedTwice && !p->unit.name(a)) a.mode = lt::kFused;
   a.wide = (p->want_wide && p->wide_ok && !a.masked && a.coll == LT_COLLISION_BGK) ? 1 : 0;
   a.shift = a.wide ? p->shift : 0;

@@ -577,28 +577,6 @@ __device__ __forceinline__ void lower_boundaries_on_moments(const KParams<T> &p,
   }
 }
 
-// (rho, j) of the node next to an outlet plane, as Flow.rho()/Flow.u() would see it when the
-// AntiBounceBackOutlet with index `slot` is evaluated: after collision (which conserves both)
-// and after the boundaries with a lower index (anti_bounce_back_outlet.py:77-80).
-template <typename T, class S, int LAYOUT, bool STREAM, bool MASKED>
-__device__ __forceinline__ void neighbour_moments(const KParams<T> &p, int c0, int c1, int c2, int slot,
-                                                  T &rho, T (&j)[3]) {
-  const Coord c = make_coord(p, c0, c1, c2);
-  T g[S::Q][1];
-  gather<T, S, LAYOUT, STREAM, 1, 0>(p, c, g);
-  const unsigned own = (unsigned)(c2 * p.n1 + c1) * (unsigned)p.n0 + (unsigned)c0;
-  int b = 0;
-  if constexpr (MASKED) {
-    const unsigned char nd = p.node[own];
-    b = nd & 0x7f;
-    if constexpr (STREAM) {
-      if (nd & 0x80) keep_unstreamed<T, S, 1, 0>(p, own, g);
-    }
-  }
-  moments<T, S, LAYOUT, 1, 0>(g, rho, j);
-  lower_boundaries_on_moments<T, S, LAYOUT>(p, b, slot, own, rho, j);
-}
-
 // AntiBounceBackOutlet (lettuce/ext/_boundary/anti_bounce_back_outlet.py:72-91) on one node
 // of the outlet plane, given (rho, j) of the node next to it (neighbour_moments).
 template <typename T, class S, int LAYOUT, int VEC, int k>
@@ -630,19 +608,83 @@ __device__ __forceinline__ void abb_apply(const KParams<T> &p, int slot, T rn, c
   });
 }
 
-template <typename T, class S, int LAYOUT, bool STREAM, bool MASKED, int VEC, int k>
+// (rho, j) of the node (c0, c1, c2), as Flow.rho()/Flow.u() would see it when the AntiBounceBackOutlet with
+// index `slot` is evaluated: after collision (which conserves both) and after the boundaries with a lower
+// index (anti_bounce_back_outlet.py:77-80).  DEPTH = how many OTHER outlets with a lower index may touch
+// this node (plans with several outlets whose planes meet in an edge): there the lower outlet has already
+// rewritten some of this node's populations, so the node's state is rebuilt in full -- pull, collision,
+// boundaries below `slot` in order, the lower outlet with ITS neighbour's moments at DEPTH - 1 -- instead
+// of being read off the conserved moments.  DEPTH = 0 is the kernel of plans with one outlet.
+template <typename T, class S, int LAYOUT, bool STREAM, bool MASKED, int COLL = 0, int DEPTH = 0>
+__device__ __forceinline__ void neighbour_moments(const KParams<T> &p, int c0, int c1, int c2, int slot,
+                                                  T &rho, T (&j)[3]) {
+  const Coord c = make_coord(p, c0, c1, c2);
+  T g[S::Q][1];
+  gather<T, S, LAYOUT, STREAM, 1, 0>(p, c, g);
+  const unsigned own = (unsigned)(c2 * p.n1 + c1) * (unsigned)p.n0 + (unsigned)c0;
+  int b = 0;
+  if constexpr (MASKED) {
+    const unsigned char nd = p.node[own];
+    b = nd & 0x7f;
+    if constexpr (STREAM) {
+      if (nd & 0x80) keep_unstreamed<T, S, 1, 0>(p, own, g);
+    }
+  }
+  if constexpr (DEPTH > 0) {
+    bool touched = false;                      // does an outlet with a lower index rewrite this node?
+    for (int t = 1; t < slot; ++t)
+      if (p.bt->kind[t] == kAbbOutlet) {
+        const int ax = p.bt->mem_axis[t];
+        touched = touched || (ax == 0 ? c0 : (ax == 1 ? c1 : c2)) == p.bt->plane[t];
+      }
+    if (touched) {
+      if (b == 0) {
+        if constexpr (COLL == 1) collide_bgk<T, S, LAYOUT, 1, 0>(g, p.tau_inv);
+        if constexpr (COLL == 2) collide_kbc<T, S, LAYOUT, 1, 0>(g, p.beta, p.inv_beta);
+      }
+      for (int t = 1; t < slot; ++t) {
+        const int kind = p.bt->kind[t];
+        if (kind == kAbbOutlet) {
+          const int ax = p.bt->mem_axis[t], nbr = p.bt->nbr[t];
+          if ((ax == 0 ? c0 : (ax == 1 ? c1 : c2)) == p.bt->plane[t]) {
+            T rn, jn[3];
+            neighbour_moments<T, S, LAYOUT, STREAM, MASKED, COLL, DEPTH - 1>(
+                p, ax == 0 ? nbr : c0, ax == 1 ? nbr : c1, ax == 2 ? nbr : c2, t, rn, jn);
+            abb_apply<T, S, LAYOUT, 1, 0>(p, t, rn, jn, g);
+          }
+        } else if (b == t) {
+          if (kind == kBounceBack) {
+            bounce_back<T, S, 1, 0>(g);
+          } else if (kind == kEquilibrium) {
+            const T *fld = p.bt->field[t];
+            static_for<S::Q>([&](auto qc) {
+              constexpr int q = decltype(qc)::value;
+              g[q][0] = fld ? fld[(long long)q * p.N + own] : p.bt->feq[t][q];
+            });
+          }
+        }
+      }
+      moments<T, S, LAYOUT, 1, 0>(g, rho, j);
+      return;
+    }
+  }
+  moments<T, S, LAYOUT, 1, 0>(g, rho, j);
+  lower_boundaries_on_moments<T, S, LAYOUT>(p, b, slot, own, rho, j);
+}
+
+template <typename T, class S, int LAYOUT, bool STREAM, bool MASKED, int VEC, int k, int COLL = 0, int ABBD = 0>
 __device__ __forceinline__ void abb_outlet(const KParams<T> &p, int slot, int c0k, int c1,
                                            int c2, T (&f)[S::Q][VEC]) {
   const int ax = p.bt->mem_axis[slot], nbr = p.bt->nbr[slot];
   T rn, jn[3];
-  neighbour_moments<T, S, LAYOUT, STREAM, MASKED>(p, ax == 0 ? nbr : c0k, ax == 1 ? nbr : c1,
-                                                   ax == 2 ? nbr : c2, slot, rn, jn);
+  neighbour_moments<T, S, LAYOUT, STREAM, MASKED, COLL, ABBD>(p, ax == 0 ? nbr : c0k, ax == 1 ? nbr : c1,
+                                                               ax == 2 ? nbr : c2, slot, rn, jn);
   abb_apply<T, S, LAYOUT, VEC, k>(p, slot, rn, jn, f);
 }
 
 // The boundaries of one node in index order (lettuce/_simulation.py:183-188); b = the node's index in
 // no_collision_mask, (c0k, c1, c2) its memory coordinates, ownk its index within a population.
-template <typename T, class S, int LAYOUT, bool STREAM, int VEC, int k>
+template <typename T, class S, int LAYOUT, bool STREAM, int VEC, int k, int COLL = 0, int ABBD = 0>
 __device__ __forceinline__ void apply_boundaries(const KParams<T> &p, int b, int c0k, int c1, int c2,
                                                  unsigned ownk, T (&f)[S::Q][VEC]) {
   for (int slot = 1; slot <= p.nb; ++slot) {
@@ -654,7 +696,7 @@ __device__ __forceinline__ void apply_boundaries(const KParams<T> &p, int b, int
       const int ax = p.bt->mem_axis[slot];
       const int coord = ax == 0 ? c0k : (ax == 1 ? c1 : c2);
       if (coord == p.bt->plane[slot])
-        abb_outlet<T, S, LAYOUT, STREAM, true, VEC, k>(p, slot, c0k, c1, c2, f);
+        abb_outlet<T, S, LAYOUT, STREAM, true, VEC, k, COLL, ABBD>(p, slot, c0k, c1, c2, f);
     } else if (b == slot) {
       if (kind == kBounceBack) {
         bounce_back<T, S, VEC, k>(f);
@@ -682,8 +724,9 @@ constexpr int crossing_rank() {
   return r;
 }
 
+// ABBD: plans with ABBD + 1 anti-bounce-back outlets (neighbour_moments, DEPTH)
 template <typename T, class S, int LAYOUT, int COLL, bool STREAM, bool COLLIDE, bool MASKED,
-          int VEC, int SHIFT, int TUNE = 0, bool PACK = false>
+          int VEC, int SHIFT, int TUNE = 0, bool PACK = false, int ABBD = 0>
 __device__ __forceinline__ void lbm_body(const KParams<T> &p) {
   const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= p.nvec_total) return;
@@ -727,7 +770,7 @@ __device__ __forceinline__ void lbm_body(const KParams<T> &p) {
         if constexpr (COLL == 2) collide_kbc<T, S, LAYOUT, VEC, k>(f, p.beta, p.inv_beta);
       }
       if constexpr (MASKED)
-        apply_boundaries<T, S, LAYOUT, STREAM, VEC, k>(p, b, c0 + k, c1, c2, own + k, f);
+        apply_boundaries<T, S, LAYOUT, STREAM, VEC, k, COLL, ABBD>(p, b, c0 + k, c1, c2, own + k, f);
     });
   }
 
@@ -756,9 +799,9 @@ __device__ __forceinline__ void lbm_body(const KParams<T> &p) {
 }
 
 template <typename T, class S, int LAYOUT, int COLL, bool STREAM, bool COLLIDE, bool MASKED,
-          int VEC, int SHIFT, int TUNE = 0, bool PACK = false>
+          int VEC, int SHIFT, int TUNE = 0, bool PACK = false, int ABBD = 0>
 __global__ void __launch_bounds__(kThreads) lbm_kernel(const KParams<T> p) {
-  lbm_body<T, S, LAYOUT, COLL, STREAM, COLLIDE, MASKED, VEC, SHIFT, TUNE, PACK>(p);
+  lbm_body<T, S, LAYOUT, COLL, STREAM, COLLIDE, MASKED, VEC, SHIFT, TUNE, PACK, ABBD>(p);
 }
 
 // same kernel with the register allocator told to fit 4 waves per SIMD (<= 128 VGPRs): the masked

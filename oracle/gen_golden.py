@@ -302,6 +302,59 @@ def operator_cases():
 
 
 # --------------------------------------------------------------------------- #
+def two_outlets_case(name, res, stencil, dt):
+    """A flow with TWO anti-bounce-back outlets (+x and +y faces, which meet in an edge), an equilibrium
+    inlet on x = 0 and a bounce-back block: the reference accepts any list of boundaries
+    (lettuce/_simulation.py:57-86); among equal classes the order is that of the objects' addresses
+    (str(b) of the default repr), so the order this run produced is stored with the vectors."""
+    if not wanted(name):
+        return
+    ctx = lt.Context(device="cpu", dtype=DT[dt], use_native=False)
+    d = stencil.d
+
+    class TwoOutlets(lt.TaylorGreenVortex):
+        made = None
+
+        @property
+        def boundaries(self):
+            if self.made is None:
+                x = self.grid[0]
+                block = torch.zeros(self.resolution, dtype=torch.bool)
+                block[tuple(slice(n // 2 - 1, n // 2 + 1) for n in self.resolution)] = True
+                inlet = [0.3] + [0.0] * (d - 1)
+                self.made = [lt.EquilibriumBoundaryPU(self.context, torch.abs(x) < 1e-6, inlet),
+                             lt.AntiBounceBackOutlet([1] + [0] * (d - 1), self),
+                             lt.AntiBounceBackOutlet([0, 1] + [0] * (d - 2), self),
+                             lt.BounceBackBoundary(block)]
+            return self.made
+    flow = quiet(TwoOutlets, ctx, res, 100, 0.05, stencil)
+    tau = flow.units.relaxation_parameter_lu
+    sim = quiet(lt.Simulation, flow, lt.BGKCollision(tau), [])
+    out = {"f0": npy(flow.f)}
+    for i in range(1, 7):
+        quiet(sim, 1)
+        if i in (1, 2, 6):
+            out[f"f{i}"] = npy(flow.f)
+    kinds, dirs = [], []
+    for b in sim.boundaries[1:]:
+        kinds.append(type(b).__name__)
+        # the reference's outlet keeps `index` (-1 / 0 on its axis, slices elsewhere), not the direction
+        index = getattr(b, "index", None)
+        dirs.append([0] * d if index is None else
+                    [0 if isinstance(i, slice) else (1 if i == -1 else -1) for i in index])
+    eq = [b for b in sim.boundaries[1:] if type(b).__name__ == "EquilibriumBoundaryPU"][0]
+    bb = [b for b in sim.boundaries[1:] if type(b).__name__ == "BounceBackBoundary"][0]
+    save(name, tau=np.float64(tau), boundary_order=np.array(kinds), boundary_direction=np.array(dirs),
+         inlet_mask=npy(eq.make_no_collision_mask(list(flow.resolution), ctx)),
+         inlet_velocity_pu=np.array([0.3] + [0.0] * (d - 1)),
+         block_mask=npy(bb.make_no_collision_mask(list(flow.resolution), ctx)),
+         u_char_lu=np.float64(flow.units.characteristic_velocity_lu),
+         no_collision_mask=npy(sim.no_collision_mask),
+         no_streaming_mask=np.packbits(npy(sim.no_streaming_mask).astype(bool), axis=None),
+         no_streaming_mask_shape=np.array(sim.no_streaming_mask.shape),
+         resolution=np.array(flow.resolution), **out)
+
+
 def shear3d_case(dt):
     """cfg5 physics: a build-defined periodic 3-D shear layer run
     through the reference Simulation, so that step parity is pinned even though
@@ -368,6 +421,9 @@ if __name__ == "__main__":
                   4.0, (1.3, 1.6, 12.0), 0.7)
     obstacle_case("obstacle3d_d3q19_bgk_10x8x32_f64", [10, 8, 32], lt.D3Q19(), "f64", "bgk", {1, 2, 3, 8},
                   4.0, (1.3, 1.6, 6.0), 0.7)
+    two_outlets_case("two_outlets_d2q9_bgk_f64", [12, 10], lt.D2Q9(), "f64")
+    two_outlets_case("two_outlets_d3q19_bgk_f64", [8, 7, 6], lt.D3Q19(), "f64")
+    two_outlets_case("two_outlets_d3q19_bgk_f32", [8, 7, 6], lt.D3Q19(), "f32")
     if wanted("native") or wanted("hand"):
         hand_set_cases()
     if wanted("operators"):

@@ -336,6 +336,45 @@ def test_slab_driver_with_an_outlet_along_z_on_gpu():
     np.testing.assert_allclose(whole.f.cpu().numpy(), want.f.numpy(), rtol=0, atol=1e-13)
 
 
+def test_flow_with_two_outlets_native_equals_the_reference_path():
+    """lt.Simulation on a native context with two AntiBounceBackOutlets == the non-native (reference) path of the
+    mirror on the CPU, for both orders of the two outlets (str() decides the order, as in the reference)."""
+    res = [10, 8, 6]
+
+    def build(c, first):
+        class OutX(lt.AntiBounceBackOutlet):
+            def __str__(self):
+                return "outlet-" + ("a" if first == "x" else "b")
+
+        class OutY(lt.AntiBounceBackOutlet):
+            def __str__(self):
+                return "outlet-" + ("b" if first == "x" else "a")
+
+        class TwoOutlets(lt.TaylorGreenVortex):
+            made = None
+
+            @property
+            def boundaries(self):
+                if self.made is None:
+                    x = self.grid[0]
+                    block = torch.zeros(res, dtype=torch.bool, device=self.context.device)
+                    block[4:6, 3:5, 2:4] = True
+                    self.made = [lt.EquilibriumBoundaryPU(self.context, torch.abs(x) < 1e-6, [0.3, 0.0, 0.0]),
+                                 OutX([1, 0, 0], self), OutY([0, 1, 0], self), lt.BounceBackBoundary(block)]
+                return self.made
+        return TwoOutlets(c, res, 100, 0.05, lt.D3Q19())
+    for first in ("x", "y"):
+        want = build(lt.Context("cpu", torch.float64, use_native=False), first)
+        got = build(gpu("f64"), first)
+        sw = lt.Simulation(want, lt.BGKCollision(want.units.relaxation_parameter_lu), [])
+        sg = lt.Simulation(got, lt.BGKCollision(got.units.relaxation_parameter_lu), [])
+        for sim_ in (sw, sg):
+            assert [str(b) for b in sim_.boundaries[1:] if str(b).startswith("outlet")] == ["outlet-a", "outlet-b"]
+        sw(6); sg(6)
+        assert sg._native.plan.kernel_name().endswith(", 1>")       # the two-outlet instantiation ran
+        np.testing.assert_allclose(got.f.cpu().numpy(), want.f.numpy(), rtol=0, atol=1e-12)
+
+
 def test_cfg1_simplest_tgv_energy_anchors():
     """BASELINE configs[0] = examples/00_simplest_TGV.py (D2Q9 128^2 fp64 Re 100 Ma 0.05, BGK,
     1000 steps) on the HIP engine against the reference CPU path: populations after 100 steps

@@ -577,6 +577,41 @@ def test_masked_two_step_on_obstacle_vectors_of_the_reference(name, lat, dt, sna
         assert_close(paired, g[f"f{n}"], dt)
 
 
+TWO_OUTLETS = [("two_outlets_d2q9_bgk_f64", "D2Q9", "f64"), ("two_outlets_d3q19_bgk_f64", "D3Q19", "f64"),
+               ("two_outlets_d3q19_bgk_f32", "D3Q19", "f32")]
+
+
+@pytest.mark.parametrize("name,lat,dt", TWO_OUTLETS, ids=[t[0] for t in TWO_OUTLETS])
+def test_two_anti_bounce_back_outlets_against_the_reference(name, lat, dt):
+    """Plans with two outlets whose planes meet in an edge (reference: any list of boundaries,
+    lettuce/_simulation.py:57-86, anti_bounce_back_outlet.py:22-103): on that edge the second outlet's neighbour
+    has already been rewritten by the first one, so its state is rebuilt in full (neighbour_moments, DEPTH 1)."""
+    g = golden(name)
+    L = orc.LATTICES[lat]
+    dtype = TORCH_DT[dt]
+    units = orc.tgv_units([int(r) for r in g["resolution"]], 100, 0.05)
+    e, w = orc.lattice_tensors(L, dtype)
+    feq_in = orc.quadratic_equilibrium(units.pressure_pu_to_density_lu(torch.tensor(0, dtype=dtype)),
+                                       units.velocity_to_lu(torch.tensor(g["inlet_velocity_pu"], dtype=dtype)), e, w)
+    entries = []
+    for kind, direction in zip(g["boundary_order"].tolist(), g["boundary_direction"].tolist()):
+        if kind == "AntiBounceBackOutlet":
+            axis = [i for i, c in enumerate(direction) if c][0]
+            entries.append({"kind": "abb_outlet", "axis": axis, "side": direction[axis]})
+        elif kind == "BounceBackBoundary":
+            entries.append({"kind": "bounce_back"})
+        else:
+            entries.append({"kind": "equilibrium", "feq": feq_in.double().tolist()})
+    plan = plan_for(lat, dtype, "bgk", g["f0"].shape[1:], entries)
+    plan.set_masks(dev(g["no_collision_mask"]), dev(unpack_nsm(g)))
+    assert plan.kernel_name().endswith(", 1>")               # the two-outlet instantiation
+    for n in (1, 2, 6):
+        got = run_engine(plan, g["f0"], float(g["tau"]), n)
+        assert_close(got, g[f"f{n}"], dt, scale=10 if dt == "f64" else 1)
+    with pytest.raises(Exception, match="more than two"):
+        plan_for(lat, dtype, "bgk", g["f0"].shape[1:], entries + [{"kind": "abb_outlet", "axis": 0, "side": -1}])
+
+
 BIT_IDENTICAL = [t for t in TGV if t[2] == "bgk"]
 
 
