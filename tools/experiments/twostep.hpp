@@ -278,6 +278,25 @@ lbm2v_kernel(const KParams<T> p, const int seg_len) {
 
   // roles are uniform per wave: branch on scalar registers
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // DBG 256: start / end time of every workgroup (100 MHz constant clock) into the buffer behind p.nsm_bits,
+  // plus the XCC id: how evenly do the 256 workgroups of a launch finish?
+  unsigned long long t_start = 0;
+  if constexpr (DBG & 256) t_start = __builtin_amdgcn_s_memrealtime();
+  struct Stamp {
+    const KParams<T> &p; unsigned long long t0; int tid;
+    __device__ ~Stamp() {
+      if constexpr (DBG & 256) {
+        if (tid == 0) {
+          unsigned long long *buf = reinterpret_cast<unsigned long long *>(const_cast<unsigned *>(p.nsm_bits));
+          unsigned xcc;
+          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+          buf[3 * blockIdx.x] = t0;
+          buf[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+          buf[3 * blockIdx.x + 2] = xcc & 0xf;
+        }
+      }
+    }
+  } stamp{p, t_start, tid};
   if (wave >= NO / 64) {
     sweep(std::false_type{}, std::false_type{});
   } else {

@@ -24,6 +24,24 @@ static int go(const void *in, void *out, int n0, int n1, int n2, double tau, int
   return (int)hipGetLastError();
 }
 
+// per-workgroup start / end stamps of one launch of the BGK kernel (DBG 256); stamps: 3 * grid uint64 on the device
+extern "C" int lt_twostep_stamps(const void *in, void *out, int n0, int n1, int n2, double tau, int seg, void *stamps,
+                                 void *stream) {
+  using T = float; using S = D3Q19;
+  using B = TwoStep<T, S, 64, 8>;
+  KParams<T> p;
+  memset(&p, 0, sizeof p);
+  p.in = (const T *)in; p.out = (T *)out;
+  p.n0 = n0; p.n1 = n1; p.n2 = n2; p.nv0 = n0; p.wrap2 = 1;
+  p.p_begin = 0; p.p_end = n2;
+  p.N = (long long)n0 * n1 * n2;
+  p.tau_inv = (T)(1.0 / tau);
+  p.nsm_bits = (const unsigned *)stamps;
+  const unsigned grid = (unsigned)((n0 / 64) * (n1 / 8) * ((n2 + seg - 1) / seg));
+  hipLaunchKernelGGL((lbm2v_kernel<T, S, 0, 1, 64, 8, 0, false, 1, 256>), dim3(grid), dim3(B::THREADS), 0, (hipStream_t)stream, p, seg);
+  return (int)hipGetLastError();
+}
+
 extern "C" int lt_twostep_experiment(int coll, int dbg, const void *in, void *out, int n0, int n1, int n2, double tau,
                                      int seg, void *stream) {
   hipStream_t st = (hipStream_t)stream;
