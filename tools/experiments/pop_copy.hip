@@ -5,7 +5,7 @@
 
 template <int Q, int ROWS, bool NTL, bool BAR, bool PREFETCH>
 __global__ void __launch_bounds__(256 * ROWS) pop_copy(const float *__restrict__ in, float *__restrict__ out, int n1, int n2,
-                                                       int seg) {
+                                                       int seg, int plane_pad) {
   extern __shared__ float dummy[];
   constexpr int n0 = 256;
   const int tid = threadIdx.x;
@@ -13,7 +13,9 @@ __global__ void __launch_bounds__(256 * ROWS) pop_copy(const float *__restrict__
   const int b = blockIdx.x;
   const int row0 = (b % groups1) * ROWS;
   const int s = (b / groups1) * seg;
-  const size_t plane = (size_t)n0 * n1, N = plane * n2;
+  // plane_pad: floats between consecutive planes (a padded, engine-owned layout): does the fixed offset of a
+  // workgroup's rows within every 256 KB plane pin it to a few memory channels?
+  const size_t plane = (size_t)n0 * n1 + plane_pad, N = plane * n2;
   const size_t own = (size_t)row0 * n0 + tid;
   float cur[Q], nxt[Q];
   auto load = [&](int k, float (&r)[Q]) {
@@ -39,17 +41,18 @@ __global__ void __launch_bounds__(256 * ROWS) pop_copy(const float *__restrict__
 }
 
 template <int ROWS, bool NTL, bool BAR, bool PREFETCH>
-static int go(const float *in, float *out, int n1, int n2, int seg, int lds, hipStream_t st) {
+static int go(const float *in, float *out, int n1, int n2, int seg, int lds, hipStream_t st, int plane_pad) {
   const unsigned grid = (unsigned)((n1 / ROWS) * (n2 / seg));
   (void)hipFuncSetAttribute((const void *)pop_copy<19, ROWS, NTL, BAR, PREFETCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((pop_copy<19, ROWS, NTL, BAR, PREFETCH>), dim3(grid), dim3(256 * ROWS), lds, st, in, out, n1, n2, seg);
+  hipLaunchKernelGGL((pop_copy<19, ROWS, NTL, BAR, PREFETCH>), dim3(grid), dim3(256 * ROWS), lds, st, in, out, n1, n2, seg, plane_pad);
   return (int)hipGetLastError();
 }
 
 // variant = rows * 100 + ntl * 10 + bar * 2 + prefetch
-extern "C" int lt_pop_copy(int variant, const float *in, float *out, int n1, int n2, int seg, int lds, void *stream) {
+extern "C" int lt_pop_copy(int variant, const float *in, float *out, int n1, int n2, int seg, int lds, void *stream,
+                           int plane_pad) {
   hipStream_t st = (hipStream_t)stream;
-#define V(R, N, B, P) if (variant == R * 100 + N * 10 + B * 2 + P) return go<R, (N != 0), (B != 0), (P != 0)>(in, out, n1, n2, seg, lds, st);
+#define V(R, N, B, P) if (variant == R * 100 + N * 10 + B * 2 + P) return go<R, (N != 0), (B != 0), (P != 0)>(in, out, n1, n2, seg, lds, st, plane_pad);
   V(1, 0, 0, 0) V(1, 1, 0, 0) V(1, 0, 0, 1) V(1, 1, 0, 1) V(2, 0, 0, 0) V(2, 1, 0, 0) V(2, 0, 0, 1) V(2, 1, 0, 1) V(2, 1, 1, 1)
   V(4, 0, 0, 0) V(4, 1, 0, 0) V(4, 1, 0, 1) V(4, 1, 1, 1) V(4, 0, 1, 1)
   return -1;
