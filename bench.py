@@ -76,9 +76,13 @@ def parse(argv=None):
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the untimed re-run with the one-step kernel (profiling passes)")
     ap.add_argument("--no-overlap", action="store_true", help="slab path: exchange without overlap")
-    ap.add_argument("--transport", choices=["auto", "rccl", "window"], default="auto",
-                    help="slab path: ghost-plane transport (lettuce_amd/_slab.py); auto = run the "
-                         "warm-up with both, require bit-identical populations, keep the faster")
+    ap.add_argument("--transport", choices=["auto", "all", "rccl", "window"],
+                    default=os.environ.get("LT_BENCH_TRANSPORT", "auto"),
+                    help="slab path: ghost-plane transport (lettuce_amd/_slab.py).  auto = RCCL send/recv only "
+                         "(both slab drivers are tried in the warm-up, results must be bit-identical, the faster "
+                         "one is timed); all = also the one-sided peer-window transports, which are faster in "
+                         "the one-GPU rehearsal but have never run across real xGMI links and end in a device "
+                         "trap if a signal is lost -- opt in with --transport all or LT_BENCH_TRANSPORT=all")
     ap.add_argument("--driver", choices=["auto", "single-step", "two-step"], default="auto",
                     help="slab path: restrict the candidates to one slab driver")
     ap.add_argument("--slab", action="store_true",
@@ -301,12 +305,12 @@ def main():
         # steps from the same initial state (two timed batches of max(W, 60) steps, max over ranks), must end with populations
         # bit-identical to the reference's on every rank, and the fastest eligible one runs the
         # timed K steps.  All warm-up rates go into the JSON line.
-        transports = ["rccl", "window"] if args.transport == "auto" else [args.transport]
+        transports = {"auto": ["rccl"], "all": ["rccl", "window"]}.get(args.transport, [args.transport])
         drivers = ["two-step", "single-step"] if args.driver == "auto" else [args.driver]
         wanted = [(d, t) for d in drivers for t in transports]
         if "two-step" in drivers and "window" in transports:
             wanted.insert(wanted.index(("two-step", "window")) + 1, ("two-step", "window-fused"))
-        if args.driver == "auto" and args.transport == "auto":
+        if args.driver == "auto" and args.transport in ("auto", "all"):
             wanted = [("single-step", "rccl")] + [w for w in wanted if w != ("single-step", "rccl")]
         finals, probe = {}, {}
         window_ok = None
