@@ -109,7 +109,13 @@ class TaylorGreenVortex(ExtFlow):
     def analytic_solution(self, t: float) -> (torch.Tensor, torch.Tensor):
         if t > 0 and self.stencil.d > 2:
             warnings.warn("The analytic solution is only true for the 2D TGV!")
-        g = self.grid
+        # The reference evaluates sin / cos on the meshgrid (taylorgreen.py:69-95), i.e. on whole fields;
+        # the functions are elementwise, so evaluating them on the 1-D axes and broadcasting the products
+        # gives the same values with d + 1 field-sized results instead of a dozen temporaries
+        # (a 512 x 512 x 70 slab is initialised per rank)
+        axes = _periodic_axes(self.resolution, 2 * torch.pi, self.context, getattr(self, "slab", None))
+        d = len(axes)
+        g = [a.reshape([-1 if k == i else 1 for k in range(d)]) for i, a in enumerate(axes)]
         nu = self.context.convert_to_tensor(self.units.viscosity_pu)
         if len(self.resolution) == 2:
             decay_u, decay_p = torch.exp(-2 * nu * t), torch.exp(-4 * nu * t)
@@ -119,7 +125,7 @@ class TaylorGreenVortex(ExtFlow):
         else:
             u = torch.stack([torch.sin(g[0]) * torch.cos(g[1]) * torch.cos(g[2]),
                              -torch.cos(g[0]) * torch.sin(g[1]) * torch.cos(g[2]),
-                             torch.zeros_like(g[0])])
+                             torch.zeros(self.resolution, dtype=self.context.dtype, device=self.context.device)])
             p = torch.stack([1 / 16. * (torch.cos(2 * g[0]) + torch.cos(2 * g[1]))
                              * (torch.cos(2 * g[2]) + 2)])
         return p, u
