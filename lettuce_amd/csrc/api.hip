@@ -242,6 +242,12 @@ int resolve_lds(const lt_plan *p, long long workgroups) {
 // the two-step tile (the rule of unit.inc): rows of 256 bytes, 8 or 4 of them; rows = 0: no kernel
 struct TwoStepTile { int width, rows; };
 TwoStepTile two_step_tile(const lt_plan *p) {
+  if (p->unit.d == 2) {
+    // 2-D (twostep2d.hpp): strips of `width` columns, the widest that divides the contiguous extent; one "row"
+    for (int w = 512; w >= 64; w /= 2)
+      if (p->n0 % w == 0) return {w, 1};
+    return {0, 0};
+  }
   const long long per_node = (long long)p->esize * 3 * p->unit.q;
   const int width = 256 / p->esize;
   const int rows = per_node * (width + 2) * 10 <= 160 * 1024
@@ -257,8 +263,14 @@ TwoStepTile two_step_tile(const lt_plan *p) {
 int resolve_seg_len(const lt_plan *p, int planes) {
   if (p->seg_len > (p->masked ? 1 : 0)) return p->seg_len;
   const TwoStepTile tile = two_step_tile(p);
-  const long long tiles = (long long)(p->n0 / tile.width) * (p->n1 / (tile.rows ? tile.rows : 8));
-  const long long cus = p->n_cu > 0 ? p->n_cu : 256;
+  long long tiles = (long long)(p->n0 / tile.width) * (p->n1 / (tile.rows ? tile.rows : 8));
+  long long cus = p->n_cu > 0 ? p->n_cu : 256;
+  if (p->unit.d == 2) {
+    // the sweep runs along a1.  Two workgroups would fit a CU in fp32 (27 row slots of width + 2 values =
+    // 55 KB), but one per CU streams better: 4096^2 fp32 0.118 ms per update with 256 workgroups of 128 rows
+    // against 0.159 with 512 of 64 (tools/two_step_2d_probe.py)
+    tiles = p->n0 / tile.width;
+  }
   int best = 1;
   double best_score = -1.0;
   for (int len = p->masked ? 2 : 1; len <= planes; ++len) {   // masked: the outlet's plane never opens a segment
@@ -374,7 +386,8 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.shift = a.wide ? p->shift : 0;
   a.tune = resolve_tune(p, a.wide);
   a.lds_bytes = resolve_lds(p, ((long long)a.planes * a.n1 * a.n0 + 255) / 256);
-  a.seg_len = mode == lt::kFusedTwice ? resolve_seg_len(p, a.planes) : 0;
+  a.seg_len = mode == lt::kFusedTwice ? resolve_seg_len(p, p->unit.d == 2 ? p->n1 : a.planes) : 0;
+  a.strip = p->unit.d == 2 ? two_step_tile(p).width : 0;
   if (mode == lt::kFusedTwice) a.shift = p->shift;      // tile-shape A/B variant
   if (mode == lt::kFusedMany) a.seg_len = p->many_now;
   a.stream = static_cast<hipStream_t>(stream);
@@ -461,6 +474,7 @@ bool two_step_wanted(lt_plan *p) {
   memset(&a, 0, sizeof a);
   a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = lt::kFusedTwice;
   a.masked = p->masked;
+  a.strip = p->unit.d == 2 ? tile.width : 0;
   if (!p->unit.name(a)) return false;
   if (p->two_step == 1) return true;
   const long long bytes = 2ll * p->unit.q * p->N * p->esize;
@@ -821,6 +835,7 @@ const char *lt_plan_kernel_name(lt_plan *p) {
   if (many_step_wanted(p)) a.mode = lt::kFusedMany;
   a.masked = p->masked;
   a.abb_depth = p->n_abb > 1 ? p->n_abb - 1 : 0;
+  a.strip = p->unit.d == 2 ? two_step_tile(p).width : 0;
   if (a.mode == lt::kFusedTwice && !p->unit.name(a)) a.mode = lt::kFused;
   a.wide = (p->want_wide && p->wide_ok && !a.masked && a.coll == LT_COLLISION_BGK) ? 1 : 0;
   a.shift = a.wide ? p->shift : 0;
@@ -961,9 +976,10 @@ int lt_plan_set_many_step(lt_plan *p, int32_t mode) {
 int lt_plan_set_two_step(lt_plan *p, int32_t mode, int32_t planes_per_workgroup) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (mode < -1 || mode > 1) return fail(LT_ERR_INVALID, "two-step mode %d", mode);
+  const int sweep = p->unit.d == 2 ? p->n1 : p->n2;          // extent of the sweep axis
   if (planes_per_workgroup < 0 ||
-      (planes_per_workgroup > 0 && !p->desc.ghost_planes && p->n2 % planes_per_workgroup != 0))
-    return fail(LT_ERR_INVALID, "planes per workgroup %d does not divide %d", planes_per_workgroup, p->n2);
+      (planes_per_workgroup > 0 && !p->desc.ghost_planes && sweep % planes_per_workgroup != 0))
+    return fail(LT_ERR_INVALID, "planes per workgroup %d does not divide %d", planes_per_workgroup, sweep);
   p->two_step = mode;
   p->seg_len = planes_per_workgroup;
   return LT_OK;

@@ -468,6 +468,40 @@ def test_abb_outlet_after_lower_index_boundaries(lat, res, axis, side):
     np.testing.assert_allclose(got, sim.f.numpy(), rtol=0, atol=1e-12)
 
 
+# --------------------------------------------------------------------------- two steps per launch, 2-D
+@pytest.mark.parametrize("res,seg", [([8, 64], 0), ([12, 128], 4), ([7, 192], 7), ([16, 512], 0), ([6, 1024], 3),
+                                     ([1, 64], 1), ([40, 256], 10)])
+@pytest.mark.parametrize("coll", ["none", "bgk"])
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_two_step_launch_on_2d_lattices_is_bit_identical_to_two_single_steps(res, seg, coll, dt):
+    """lbm2d2_kernel (twostep2d.hpp): strips of 64 .. 512 columns, every segment length incl. 1 and rows that
+    wrap; res = [x, y] with y contiguous."""
+    dtype = TORCH_DT[dt]
+    plan = plan_for("D2Q9", dtype, coll, res)
+    plan.set_many_step(0)
+    f = dev(_random_state(orc.LATTICES["D2Q9"], res, dtype, 4))
+    a, b, c = torch.empty_like(f), torch.empty_like(f), torch.full_like(f, float("nan"))
+    plan.stream_collide(f, a, 0.7)
+    plan.stream_collide(a, b, 0.7)
+    plan.set_two_step(1, seg)
+    assert "lbm2d2_kernel" in plan.kernel_name()
+    plan.stream_collide_twice(f, c, 0.7)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(c.cpu().numpy(), b.cpu().numpy())
+
+
+def test_two_step_2d_kernel_reproduces_the_cfg1_vectors_bit_for_bit():
+    """BASELINE configs[0] (examples/00_simplest_TGV.py, 128^2 fp64) through the 2-D two-step kernel: the
+    reference's populations after 100 steps, exactly."""
+    g = golden("tgv2d_d2q9_bgk_128_f64")
+    plan = plan_for("D2Q9", torch.float64, "bgk", [128, 128])
+    plan.set_many_step(0)
+    plan.set_two_step(1)
+    np.testing.assert_array_equal(run_engine(plan, g["f0"], float(g["tau"]), 100), g["f100"])
+    info = plan.last_run_info()
+    assert info["two_step_launches"] == 49 and info["single_step_launches"] == 1 and info["many_step_launches"] == 0
+
+
 # --------------------------------------------------------------------------- two steps per launch, with boundaries
 def _masked_case(lat, res, dtype, abb, seed, with_field=False, abb_first=False):
     """Random bounce-back and equilibrium nodes (the latter optionally with a per-node field) plus one
