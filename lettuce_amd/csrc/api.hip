@@ -95,7 +95,8 @@ struct lt_plan {
   double *partial = nullptr;
   int masked = 0;
   int n_abb = 0;             // anti-bounce-back outlets of the plan
-  int nsm_confined = 1;      // every no-streaming bit lies on the anti-bounce-back outlet's plane (lt_plan_set_masks)
+  int nsm_confined = 1;      // the no-streaming bits are exactly those of the plan's outlet (lt_plan_set_masks)
+  int inlet_faces_outlet = 1;  // outlet along a0: every node of the opposite face is an equilibrium node
   unsigned *mask_flag = nullptr;   // device word written by the mask compilation
   char kernel_name[192];
   // launch-bound grids: a captured hipGraph of kGraphChunk fused steps (ping-pong returns to the
@@ -181,6 +182,19 @@ lt::QList crossing_of(int logical_axis, int dir) {
 
 lt::QList crossing(const lt_plan *p, int dir) {
   const int axis = p->unit.d == 2 ? 0 : (p->desc.layout == LT_LAYOUT_REFERENCE ? 0 : 2);
+  switch (p->desc.stencil) {
+    case LT_D1Q3: return crossing_of<lt::D1Q3>(0, dir);
+    case LT_D2Q9: return crossing_of<lt::D2Q9>(axis, dir);
+    case LT_D3Q15: return crossing_of<lt::D3Q15>(axis, dir);
+    case LT_D3Q19: return crossing_of<lt::D3Q19>(axis, dir);
+    default: return crossing_of<lt::D3Q27>(axis, dir);
+  }
+}
+
+// populations whose velocity component along MEMORY axis `mem_axis` equals `dir` (the axis maps are
+// involutions: mem_axis_of also takes a memory axis to its logical one)
+lt::QList crossing_axis(const lt_plan *p, int mem_axis, int dir) {
+  const int axis = mem_axis_of(p, mem_axis);
   switch (p->desc.stencil) {
     case LT_D1Q3: return crossing_of<lt::D1Q3>(0, dir);
     case LT_D2Q9: return crossing_of<lt::D2Q9>(axis, dir);
@@ -323,22 +337,28 @@ int halo2(lt_plan *p, bool do_pack, void *f, int side, void *buf, void *stream) 
 }
 
 // Two updates per launch on a plan with boundaries (lbm2m_kernel, twostep_masked.hpp): bounce-back and
-// equilibrium nodes anywhere; an anti-bounce-back outlet only at the LAST plane of the sweep axis (memory
-// axis a2, side +1 -- the reference's Obstacle in the reference layout), where its neighbour's moments and
-// its no-streaming bits reduce to tests on the plane index; and no-streaming bits exactly where that
-// outlet puts them (checked on the device when the masks are compiled).  Anything else keeps the one-step
-// kernel.
-bool masked_two_step_ok(const lt_plan *p) {
-  if (!p->nsm_confined) return false;
-  int n_abb = 0;
+// equilibrium nodes anywhere; at most one anti-bounce-back outlet, either at the LAST plane of the sweep axis
+// (memory axis a2, side +1 -- the reference's Obstacle in the reference layout), where its neighbour's moments
+// and its no-streaming bits reduce to tests on the plane index, or at an end of the rows (memory axis a0 --
+// the Obstacle in the slab layout), where the neighbour is the next lane and the face opposite the outlet
+// must consist of equilibrium nodes; and no-streaming bits exactly where that outlet puts them (both checked
+// on the device when the masks are compiled).  Anything else keeps the one-step kernel.
+// Returns the memory axis of the outlet (2 without one), or -1: not admitted.
+int masked_two_step_axis(const lt_plan *p) {
+  if (!p->nsm_confined) return -1;
+  int n_abb = 0, axis = 2;
   for (int i = 0; i < p->desc.n_boundaries; ++i) {
     const lt_boundary_desc &b = p->desc.boundaries[i];
-    if (b.kind != LT_BOUNDARY_ABB_OUTLET) continue;
-    if (++n_abb > 1) return false;
-    if (mem_axis_of(p, b.axis) != 2 || b.side != 1 || p->n2 < 3) return false;
+    if (b.kind != LT_BOUNDARY_ABB_OUTLET || (b.flags & LT_BOUNDARY_ABSENT)) continue;
+    if (++n_abb > 1) return -1;
+    axis = mem_axis_of(p, b.axis);
+    if (axis == 2 && (b.side != 1 || p->n2 < 3)) return -1;
+    if (axis == 0 && !p->inlet_faces_outlet) return -1;
+    if (axis == 1) return -1;
   }
-  return true;
+  return axis;
 }
+bool masked_two_step_ok(const lt_plan *p) { return masked_two_step_axis(p) >= 0; }
 
 int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long pb, long long pe,
          void *stream, long long stride = 1, void *pack_lo = nullptr, void *pack_hi = nullptr) {
@@ -360,10 +380,11 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
       return fail(LT_ERR_INVALID, "two-step range [%lld, %lld) must stay in [2, %d)", pb, pe, p->n2 - 2);
     if (!p->desc.ghost_planes && (pb != 0 || pe != p->n2))
       return fail(LT_ERR_INVALID, "periodic plan: the two-step launch covers all planes");
-    if (p->masked && (p->desc.ghost_planes || !masked_two_step_ok(p)))
-      return fail(LT_ERR_UNSUPPORTED, "two steps per launch with boundaries: periodic plans whose only anti-bounce-back "
-                                      "outlet (if any) is at the last plane of the slowest memory axis, no-streaming "
-                                      "bits exactly that outlet's");
+    if (p->masked && (!masked_two_step_ok(p) || (p->desc.ghost_planes && p->n_abb > 0 && masked_two_step_axis(p) != 0)))
+      return fail(LT_ERR_UNSUPPORTED, "two steps per launch with boundaries: at most one anti-bounce-back outlet, at the "
+                                      "last plane of the slowest memory axis (periodic plans only) or at an end of "
+                                      "the contiguous axis opposite a face of equilibrium nodes; no-streaming bits "
+                                      "exactly that outlet's");
   }
   if (p->desc.n_boundaries > 0 && !p->masked)
     return fail(LT_ERR_INVALID, "plan has boundaries but lt_plan_set_masks was not called");
@@ -380,6 +401,7 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = mode;
   a.masked = p->masked;
   a.abb_depth = p->n_abb > 1 ? p->n_abb - 1 : 0;
+  a.abb_axis = p->masked ? masked_two_step_axis(p) : 2;
   const bool aligned = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
   const bool hot = mode == lt::kFused && !a.masked && a.coll == LT_COLLISION_BGK;
   a.wide = (p->want_wide && hot && p->wide_ok && aligned) ? 1 : 0;
@@ -692,26 +714,35 @@ int lt_plan_set_masks(lt_plan *p, const uint8_t *ncm, const uint8_t *nsm, void *
   if (!p->mask_flag) LT_HIP(hipMalloc((void **)&p->mask_flag, sizeof(unsigned)));
   hipStream_t hs = static_cast<hipStream_t>(stream);
   LT_HIP(hipMemsetAsync(p->mask_flag, 0, sizeof(unsigned), hs));
-  // the only no-streaming bits the two-step kernel can take: those of an outlet at the last plane of the
-  // slowest memory axis -- the populations moving down that axis, on every node of that plane
-  int plane = -1;
-  unsigned expected = 0;
+  // the only no-streaming bits the two-step kernel can take: those of ONE outlet at the last plane of the
+  // slowest memory axis or at an end of the rows -- the populations entering through it, on every node of it
+  int axis = -1, plane = -1, face = -1, outlets = 0;
+  unsigned expected = 0, eq_slots = 0;
   for (int i = 0; i < p->desc.n_boundaries; ++i) {
     const lt_boundary_desc &b = p->desc.boundaries[i];
-    if (b.kind == LT_BOUNDARY_ABB_OUTLET && mem_axis_of(p, b.axis) == 2 && b.side == 1) {
-      plane = p->n2 - 1;
-      const lt::QList down = crossing(p, -1);
-      for (int k = 0; k < down.n; ++k) expected |= 1u << down.q[k];
+    if (b.kind == LT_BOUNDARY_EQUILIBRIUM) eq_slots |= 1u << (i + 1);
+    if (b.kind != LT_BOUNDARY_ABB_OUTLET || (b.flags & LT_BOUNDARY_ABSENT)) continue;
+    ++outlets;
+    const int ax = mem_axis_of(p, b.axis);
+    if ((ax == 2 && b.side == 1) || ax == 0) {
+      axis = ax;
+      plane = ax == 2 ? p->n2 - 1 - p->desc.ghost_planes : (b.side == 1 ? p->n0 - 1 : 0);
+      if (ax == 0) face = b.side == 1 ? 0 : p->n0 - 1;
+      const lt::QList in = crossing_axis(p, ax, -b.side);
+      for (int k = 0; k < in.n; ++k) expected |= 1u << in.q[k];
     }
   }
+  if (outlets != 1) { axis = -1; plane = -1; face = -1; expected = 0; }
   const unsigned grid = (unsigned)((p->N + lt::kThreads - 1) / lt::kThreads);
   hipLaunchKernelGGL(lt::compile_masks_kernel, dim3(grid), dim3(lt::kThreads), 0, hs, ncm, nsm, p->unit.q, p->N,
-                     p->node, nsm ? p->nsm_bits : nullptr, (long long)p->n0 * p->n1, plane, expected, p->mask_flag);
+                     p->node, nsm ? p->nsm_bits : nullptr, (long long)p->n0 * p->n1, p->n0, axis, plane, expected,
+                     face, eq_slots, p->mask_flag);
   LT_HIP(hipGetLastError());
-  unsigned outside = 0;
-  LT_HIP(hipMemcpyAsync(&outside, p->mask_flag, sizeof outside, hipMemcpyDeviceToHost, hs));
+  unsigned flags = 0;
+  LT_HIP(hipMemcpyAsync(&flags, p->mask_flag, sizeof flags, hipMemcpyDeviceToHost, hs));
   LT_HIP(hipStreamSynchronize(hs));
-  p->nsm_confined = outside == 0;
+  p->nsm_confined = (flags & 1u) == 0;
+  p->inlet_faces_outlet = (flags & 2u) == 0;
   p->masked = 1;
   return LT_OK;
 }
@@ -835,6 +866,7 @@ const char *lt_plan_kernel_name(lt_plan *p) {
   if (many_step_wanted(p)) a.mode = lt::kFusedMany;
   a.masked = p->masked;
   a.abb_depth = p->n_abb > 1 ? p->n_abb - 1 : 0;
+  a.abb_axis = p->masked ? masked_two_step_axis(p) : 2;
   a.strip = p->unit.d == 2 ? two_step_tile(p).width : 0;
   if (a.mode == lt::kFusedTwice && !p->unit.name(a)) a.mode = lt::kFused;
   a.wide = (p->want_wide && p->wide_ok && !a.masked && a.coll == LT_COLLISION_BGK) ? 1 : 0;

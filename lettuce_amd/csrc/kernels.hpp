@@ -1415,12 +1415,15 @@ __global__ void __launch_bounds__(kThreads) halo2_kernel(T *__restrict__ f, T *_
 }
 
 // node descriptor byte + sparse streaming-mask bits from the reference's two mask tensors
-// *mismatch is set when the no-streaming bits of a node differ from `expected` on a2 plane `plane` or
-// from zero elsewhere (the masked two-step kernel's admission test; plane < 0: no bits anywhere)
+// The masked two-step kernel's admission tests (twostep_masked.hpp), collected in *mismatch:
+//  bit 0: the no-streaming bits of a node differ from `expected` on the outlet -- a2 plane `plane` (axis = 2)
+//         or a0 column `plane` (axis = 0) -- or from zero elsewhere (axis < 0: no bits anywhere);
+//  bit 1: a node of a0 column `face` (>= 0: the face opposite an a0 outlet) is not an equilibrium node
+//         (eq_slots: bit s set = boundary s is an EquilibriumBoundaryPU).
 static __global__ void __launch_bounds__(kThreads) compile_masks_kernel(
     const unsigned char *__restrict__ ncm, const unsigned char *__restrict__ nsm, int q,
-    long long N, unsigned char *__restrict__ node, unsigned *__restrict__ bits, long long plane_nodes, int plane,
-    unsigned expected, unsigned *__restrict__ mismatch) {
+    long long N, unsigned char *__restrict__ node, unsigned *__restrict__ bits, long long plane_nodes, int n0,
+    int axis, int plane, unsigned expected, int face, unsigned eq_slots, unsigned *__restrict__ mismatch) {
   const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (i >= N) return;
   unsigned b = 0;
@@ -1428,9 +1431,14 @@ static __global__ void __launch_bounds__(kThreads) compile_masks_kernel(
     for (int k = 1; k < q; ++k)
       if (nsm[(long long)k * N + i] == 1) b |= 1u << k;
   }
-  node[i] = (unsigned char)((ncm ? (ncm[i] & 0x7f) : 0) | (b ? 0x80 : 0));
+  const int slot = ncm ? (ncm[i] & 0x7f) : 0;
+  node[i] = (unsigned char)(slot | (b ? 0x80 : 0));
   if (bits) bits[i] = b;
-  if (b != ((plane >= 0 && i / plane_nodes == plane) ? expected : 0u)) *mismatch = 1u;
+  const int c0 = (int)(i % n0);
+  const bool on_outlet = axis == 2 ? i / plane_nodes == plane : (axis == 0 ? c0 == plane : false);
+  unsigned bad = b != (on_outlet ? expected : 0u) ? 1u : 0u;
+  if (face >= 0 && c0 == face && !((eq_slots >> slot) & 1u)) bad |= 2u;
+  if (bad) atomicOr(mismatch, bad);
 }
 
 }  // namespace lt

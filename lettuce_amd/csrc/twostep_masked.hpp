@@ -15,9 +15,18 @@
 //    become a test on the plane index: at the outlet plane the downward populations are taken from the
 //    node itself (phase A: the input field; phase B: the intermediate populations in LDS, which is why
 //    the downward populations have a third LDS slot: plane k must survive interval k).
+//  * or (AX = 0) at the first / last node of the rows, i.e. with its normal along the contiguous axis a0 (the
+//    Obstacle in the slab layout, where x is contiguous): the node next to the outlet is then the
+//    neighbouring LANE of the same wave, in both phases, so its (rho, j) arrive by a lane shuffle; the
+//    outlet's no-streaming bits -- the populations entering through the outlet, on every node of it -- are
+//    a per-thread constant: those populations are read from the node itself (phase A: the source offset of
+//    the thread is set up that way; phase B: the node's own LDS slot).  The grid wraps along a0, so the
+//    outlet column is also the halo column of the tiles at the other end of the rows, whose threads have no
+//    neighbour lane: the host admits such a plan only if every node of the face opposite the outlet is an
+//    equilibrium (inlet) node, which ignores what it pulls.
 //  The host admits a plan only if its masks have exactly that shape (api.hip, masked_two_step_ok; the
-//  no-streaming bits are checked on the device when the masks are compiled); anything else -- outlets
-//  along the other axes, stray no-streaming bits, KBC -- keeps the one-step kernel.
+//  no-streaming bits and the inlet face are checked on the device when the masks are compiled); anything
+//  else -- outlets along a1, stray no-streaming bits, KBC -- keeps the one-step kernel.
 //
 // Memory side (differs from lbm2_kernel because boundary code needs registers: lbm2_kernel + masks spilled):
 //  * buffer addressing: `buffer_load/store_dword v, voffset, s[desc], soffset` with one descriptor per
@@ -70,23 +79,26 @@ constexpr size_t two_step_masked_lds() {
 // kinds of the plan's boundaries, two bits per slot, and the outlet's slot / plane (slot 0: no outlet)
 struct MaskedPlanInfo {
   unsigned kinds;
-  int abb_slot, abb_side, abb_plane;
+  int abb_slot, abb_side, abb_plane, abb_axis;
 };
 template <typename T>
 __device__ __forceinline__ MaskedPlanInfo masked_plan_info(const KParams<T> &p) {
-  MaskedPlanInfo m = {0u, 0, 1, -1};
+  MaskedPlanInfo m = {0u, 0, 1, -1, 2};
   for (int slot = 1; slot <= p.nb; ++slot) {
     const int kind = p.bt->kind[slot];
     m.kinds |= (unsigned)kind << (2 * slot);
-    if (kind == kAbbOutlet) { m.abb_slot = slot; m.abb_side = p.bt->side[slot]; m.abb_plane = p.bt->plane[slot]; }
+    if (kind == kAbbOutlet) {
+      m.abb_slot = slot; m.abb_side = p.bt->side[slot]; m.abb_plane = p.bt->plane[slot];
+      m.abb_axis = p.bt->mem_axis[slot];
+    }
   }
   return m;
 }
 
-// AntiBounceBackOutlet with its normal along memory axis a2 (anti_bounce_back_outlet.py:72-91), given
+// AntiBounceBackOutlet with its normal along memory axis AX (anti_bounce_back_outlet.py:72-91), given
 // (rho, j) of the node next to the plane; the arithmetic of abb_apply (kernels.hpp), operation for operation
-template <typename T, class S, int LAYOUT>
-__device__ __forceinline__ void abb_apply_a2(int side, T rn, const T (&jn)[3], T (&f)[S::Q][1]) {
+template <typename T, class S, int LAYOUT, int AX>
+__device__ __forceinline__ void abb_apply_ax(int side, T rn, const T (&jn)[3], T (&f)[S::Q][1]) {
   using M = MemMap<S, LAYOUT>;
   T rho, j[3];
   moments<T, S, LAYOUT, 1, 0>(f, rho, j);
@@ -101,9 +113,9 @@ __device__ __forceinline__ void abb_apply_a2(int side, T rn, const T (&jn)[3], T
   // the populations leaving through the plane (e.n = +1) are only read, their opposites only written
   static_for<S::Q>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
-    constexpr int e2 = M::e(q, 2);
-    if constexpr (e2 != 0) {
-      if (e2 * side == 1) {
+    constexpr int en = M::e(q, AX);
+    if constexpr (en != 0) {
+      if (en * side == 1) {
         const T eu = dot_e<S, LAYOUT, q>(uw);
         f[S::OPP[q]][0] = -f[q][0] + T(S::W[q]) * rho * (T(2) + eu * eu / T(kCs4) - nrm2);
       }
@@ -111,9 +123,11 @@ __device__ __forceinline__ void abb_apply_a2(int side, T rn, const T (&jn)[3], T
   });
 }
 
-template <typename T, class S, int LAYOUT, int COLL, int T0_, int T1>
+// AX: memory axis of the outlet's normal, 2 or 0 (plans without an outlet run the AX = 2 kernel)
+template <typename T, class S, int LAYOUT, int COLL, int T0_, int T1, int AX = 2>
 __global__ void __launch_bounds__((TwoStep<T, S, T0_, T1>::THREADS))
 lbm2m_kernel(const KParams<T> p, const int seg_len) {
+  static_assert(AX == 0 || AX == 2, "outlet along the sweep axis or along the rows");
   using B = TwoStep<T, S, T0_, T1>;
   using M = MemMap<S, LAYOUT>;
   constexpr int T0 = B::T0, H0 = B::H0, NI = B::NI, NO = B::NO;
@@ -137,6 +151,11 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
 
   const bool in_a = tid < NI;
   const unsigned pop_bytes = (unsigned)(p.N * (long long)sizeof(T));
+  const MaskedPlanInfo info = masked_plan_info(p);
+  // AX = 0: is this thread's intermediate (a_out) / output (b_out) node on the outlet?  tile_out (uniform):
+  // does the tile hold the outlet column among its inner columns?
+  bool a_out = false, b_out = false;
+  const bool tile_out = AX == 0 && info.abb_slot != 0 && info.abb_plane >= t0 && info.abb_plane < t0 + T0;
   // per-thread byte offsets of the source slot of every population (phase A) and of the output slot
   // (phase B) relative to the first node of the plane in population 0
   unsigned voff[S::Q], out_off[S::Q];
@@ -158,11 +177,17 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
     const int j1 = tid / T0, j0 = tid - j1 * T0;
     b_own = (unsigned)(t1 + j1) * (unsigned)p.n0 + (unsigned)(t0 + j0);
     b_at = (j1 + 1) * H0 + (j0 + 1);
+    if constexpr (AX == 0) {
+      a_out = tile_out && tid < inner && g0 == info.abb_plane;
+      b_out = tile_out && t0 + j0 == info.abb_plane;
+    }
     static_for<S::Q>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1);
-      const int y = e1 == 0 ? g1 : (e1 > 0 ? g1m : g1p);      // source = node - e
-      const int x = e0 == 0 ? g0 : (e0 > 0 ? g0m : g0p);
+      // the populations entering through an a0 outlet are not streamed: their source is the node itself
+      const bool keep = AX == 0 && e0 != 0 && a_out && e0 == -info.abb_side;
+      const int y = e1 == 0 || keep ? g1 : (e1 > 0 ? g1m : g1p);      // source = node - e
+      const int x = e0 == 0 || keep ? g0 : (e0 > 0 ? g0m : g0p);
       voff[q] = ((unsigned)y * (unsigned)p.n0 + (unsigned)x) * (unsigned)sizeof(T) + (unsigned)q * pop_bytes;
       out_off[q] = b_own * (unsigned)sizeof(T) + (unsigned)q * pop_bytes;
     });
@@ -171,7 +196,9 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   const unsigned plane_bytes = plane_nodes * (unsigned)sizeof(T);
   const __amdgpu_buffer_rsrc_t in_r = field_rsrc(p.in, (unsigned)S::Q * pop_bytes),
                                out_r = field_rsrc(p.out, (unsigned)S::Q * pop_bytes);
-  const MaskedPlanInfo info = masked_plan_info(p);
+  const bool abb_a2 = AX == 2 && info.abb_slot != 0;                  // outlet at a plane of the sweep axis
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int nbr_lane = (lane - info.abb_side) & 63;                    // AX = 0: who holds the node next to mine
 
   auto wrapped = [&](int plane) __attribute__((always_inline)) {
     return p.wrap2 ? (plane < 0 ? plane + p.n2 : (plane >= p.n2 ? plane - p.n2 : plane)) : plane;
@@ -179,14 +206,13 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
 
   // collision, then the boundaries in index order, on the post-streaming populations g of the node `own`
   // of plane g2 whose node byte is nd; (rn, jn): moments of the same column one plane earlier
-  auto collide_and_bound = [&](T (&g)[S::Q][1], int nd, int g2, unsigned own, T rn, const T (&jn)[3])
+  auto collide_and_bound = [&](T (&g)[S::Q][1], int nd, bool on_outlet, unsigned own, T rn, const T (&jn)[3])
                                __attribute__((always_inline)) {
     const int bidx = nd & 0x7f;
     if (bidx == 0) {
       if constexpr (COLL == 1) collide_bgk<T, S, LAYOUT, 1, 0>(g, p.tau_inv);
     }
-    const bool on_outlet = info.abb_slot != 0 && g2 == info.abb_plane;          // uniform
-    if (on_outlet && (bidx == 0 || info.abb_slot <= bidx)) abb_apply_a2<T, S, LAYOUT>(info.abb_side, rn, jn, g);
+    if (on_outlet && (bidx == 0 || info.abb_slot <= bidx)) abb_apply_ax<T, S, LAYOUT, AX>(info.abb_side, rn, jn, g);
     if (bidx != 0) {
       const int kind = (int)((info.kinds >> (2 * bidx)) & 3u);
       if (kind == kBounceBack) {
@@ -198,7 +224,7 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
           g[q][0] = fld ? fld[(long long)q * p.N + own] : p.bt->feq[bidx][q];
         });
       }
-      if (on_outlet && info.abb_slot > bidx) abb_apply_a2<T, S, LAYOUT>(info.abb_side, rn, jn, g);
+      if (on_outlet && info.abb_slot > bidx) abb_apply_ax<T, S, LAYOUT, AX>(info.abb_side, rn, jn, g);
     }
   };
   // (rho, j) of a node as the outlet one plane further sees it: the moments of its post-streaming
@@ -209,7 +235,12 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
     lower_boundaries_on_moments<T, S, LAYOUT>(p, nd & 0x7f, info.abb_slot, own, rho, j);
   };
   // the plane next to the outlet plane (uniform test); -2: never
-  const int abb_nbr = info.abb_slot != 0 ? info.abb_plane - info.abb_side : -2;
+  const int abb_nbr = abb_a2 ? info.abb_plane - info.abb_side : -2;
+  // AX = 0: (rho, j) of the node next to the outlet node, from the lane that holds it
+  auto from_neighbour_lane = [&](T &rho, T (&j)[3]) __attribute__((always_inline)) {
+    rho = __shfl(rho, nbr_lane);
+    j[0] = __shfl(j[0], nbr_lane); j[1] = __shfl(j[1], nbr_lane); j[2] = __shfl(j[2], nbr_lane);
+  };
 
   T pre[S::Q][1];
   int nd_pre = 0;                                    // node byte of the intermediate node being loaded
@@ -222,15 +253,20 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
       g2p = g2 == p.n2 - 1 ? 0 : g2 + 1;
     }
     const unsigned off0 = (unsigned)g2 * plane_bytes, offm = (unsigned)g2m * plane_bytes;
-    // at the outlet plane the downward populations are not streamed: they come from the node itself
-    const bool keep_down = info.abb_slot != 0 && g2 == info.abb_plane;
+    // at an a2 outlet plane the downward populations are not streamed: they come from the node itself
+    const bool keep_down = abb_a2 && g2 == info.abb_plane;
     const unsigned offp = (unsigned)(keep_down ? g2 : g2p) * plane_bytes;
     if (in_a) {
       nd_pre = p.node[(unsigned)g2 * plane_nodes + a_own];
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        constexpr int e2 = M::e(q, 2);
-        if constexpr (e2 < 0) {
+        constexpr int e0 = M::e(q, 0), e2 = M::e(q, 2);
+        if constexpr (AX == 0 && e0 != 0 && e2 != 0) {
+          // an a0 outlet node keeps the populations entering through the outlet: voff[q] already points at
+          // the node within a plane, and the plane is its own instead of the one below / above
+          const bool keep = a_out && e0 == -info.abb_side;
+          pre[q][0] = BufIO<T>::load(in_r, voff[q] + (keep ? off0 : (e2 > 0 ? offm : offp)), 0u);
+        } else if constexpr (e2 < 0) {
           const unsigned v = keep_down ? a_own * (unsigned)sizeof(T) + (unsigned)q * pop_bytes : voff[q];
           pre[q][0] = BufIO<T>::load(in_r, v, offp);
         } else {
@@ -245,9 +281,17 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
       const int g2 = wrapped(plane);
       const unsigned own = (unsigned)g2 * plane_nodes + a_own;
       T keep_rho = T(1), keep_j[3] = {T(0), T(0), T(0)};
-      if (g2 == abb_nbr) moments_for_outlet(pre, nd_pre, own, keep_rho, keep_j);
-      collide_and_bound(pre, nd_pre, g2, own, sa_rho, sa_j);
-      sa_rho = keep_rho; sa_j[0] = keep_j[0]; sa_j[1] = keep_j[1]; sa_j[2] = keep_j[2];
+      if constexpr (AX == 0) {
+        if (tile_out) {                               // uniform; the rows' waves are full
+          moments_for_outlet(pre, nd_pre, own, keep_rho, keep_j);
+          from_neighbour_lane(keep_rho, keep_j);
+        }
+        collide_and_bound(pre, nd_pre, a_out, own, keep_rho, keep_j);
+      } else {
+        if (g2 == abb_nbr) moments_for_outlet(pre, nd_pre, own, keep_rho, keep_j);
+        collide_and_bound(pre, nd_pre, abb_a2 && g2 == info.abb_plane, own, sa_rho, sa_j);
+        sa_rho = keep_rho; sa_j[0] = keep_j[0]; sa_j[1] = keep_j[1]; sa_j[2] = keep_j[2];
+      }
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr int e2 = M::e(q, 2), rank = crossing_rank<S, LAYOUT, q>();
@@ -265,23 +309,39 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   // upward populations from plane r - 1, in-plane ones from r, downward ones from r + 1 -- or, at the
   // outlet plane, from the node itself
   auto read_b = [&](int r, int r3, int k2) __attribute__((always_inline)) {
-    const bool keep_down = info.abb_slot != 0 && k2 == info.abb_plane;
+    const bool keep_down = abb_a2 && k2 == info.abb_plane;
     const int dslot = keep_down ? r3 : (r3 == 2 ? 0 : r3 + 1);
     static_for<S::Q>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1), e2 = M::e(q, 2), rank = crossing_rank<S, LAYOUT, q>();
       const int at = b_at - e1 * H0 - e0;
-      if constexpr (e2 > 0) f[q][0] = lds_u[(r - 1) & 3][rank][at];
-      else if constexpr (e2 == 0) f[q][0] = lds_c[r3][rank][at];
-      else f[q][0] = lds_d[dslot][rank][keep_down ? b_at : at];
+      if constexpr (AX == 0 && e0 != 0) {
+        // an a0 outlet node keeps the populations entering through the outlet: its own intermediate value
+        const bool keep = b_out && e0 == -info.abb_side;
+        if constexpr (e2 > 0) f[q][0] = lds_u[(keep ? r : r - 1) & 3][rank][keep ? b_at : at];
+        else if constexpr (e2 == 0) f[q][0] = lds_c[r3][rank][keep ? b_at : at];
+        else f[q][0] = lds_d[keep ? r3 : dslot][rank][keep ? b_at : at];
+      } else {
+        if constexpr (e2 > 0) f[q][0] = lds_u[(r - 1) & 3][rank][at];
+        else if constexpr (e2 == 0) f[q][0] = lds_c[r3][rank][at];
+        else f[q][0] = lds_d[dslot][rank][keep_down ? b_at : at];
+      }
     });
   };
   auto finish_b = [&](int k2) __attribute__((always_inline)) {
     const unsigned own = (unsigned)k2 * plane_nodes + b_own;
     T keep_rho = T(1), keep_j[3] = {T(0), T(0), T(0)};
-    if (k2 == abb_nbr) moments_for_outlet(f, nd_b, own, keep_rho, keep_j);
-    collide_and_bound(f, nd_b, k2, own, sb_rho, sb_j);
-    sb_rho = keep_rho; sb_j[0] = keep_j[0]; sb_j[1] = keep_j[1]; sb_j[2] = keep_j[2];
+    if constexpr (AX == 0) {
+      if (tile_out) {
+        moments_for_outlet(f, nd_b, own, keep_rho, keep_j);
+        from_neighbour_lane(keep_rho, keep_j);
+      }
+      collide_and_bound(f, nd_b, b_out, own, keep_rho, keep_j);
+    } else {
+      if (k2 == abb_nbr) moments_for_outlet(f, nd_b, own, keep_rho, keep_j);
+      collide_and_bound(f, nd_b, abb_a2 && k2 == info.abb_plane, own, sb_rho, sb_j);
+      sb_rho = keep_rho; sb_j[0] = keep_j[0]; sb_j[1] = keep_j[1]; sb_j[2] = keep_j[2];
+    }
     const unsigned off = (unsigned)k2 * plane_bytes;
     static_for<S::Q>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
@@ -295,7 +355,7 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   // The sweep of one wave.  HAS_B: the wave holds output nodes (waves below NO / 64).
   auto sweep = [&](auto has_b) __attribute__((always_inline)) {
     constexpr bool HAS_B = decltype(has_b)::value;
-    if (info.abb_slot != 0 && wrapped(s - 1) == info.abb_plane) {
+    if (abb_a2 && wrapped(s - 1) == info.abb_plane) {
       // the sweep opens ON the outlet plane (plane -1 of a periodic grid): the moments of the plane before
       // it, which the outlet needs, have not been met yet
       load_a(s - 2);

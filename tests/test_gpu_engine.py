@@ -503,15 +503,21 @@ def test_two_step_2d_kernel_reproduces_the_cfg1_vectors_bit_for_bit():
 
 
 # --------------------------------------------------------------------------- two steps per launch, with boundaries
-def _masked_case(lat, res, dtype, abb, seed, with_field=False, abb_first=False):
+def _masked_case(lat, res, dtype, abb, seed, with_field=False, abb_first=False, inlet_face=False):
     """Random bounce-back and equilibrium nodes (the latter optionally with a per-node field) plus one
-    anti-bounce-back outlet (axis, side) with the masks the reference's boundary builds; abb = None: no outlet."""
+    anti-bounce-back outlet (axis, side) with the masks the reference's boundary builds; abb = None: no outlet.
+    inlet_face: the face opposite the outlet consists of equilibrium nodes (an inlet, as in the Obstacle)."""
     L = orc.LATTICES[lat]
     g = torch.Generator().manual_seed(seed)
     f0 = _random_state(L, res, dtype, seed)
     e, w = orc.lattice_tensors(L, dtype)
     bb_mask = torch.rand(res, generator=g) < 0.2
     eq_mask = (torch.rand(res, generator=g) < 0.15) & ~bb_mask
+    if inlet_face:
+        face = [slice(None)] * L.d
+        face[abb[0]] = 0 if abb[1] == 1 else res[abb[0]] - 1
+        eq_mask[tuple(face)] = True
+        bb_mask[tuple(face)] = False
     units = orc.Units(10, 0.1)
     vel = torch.tensor([0.2, 0.1, -0.3][:L.d], dtype=dtype)
     feq = orc.quadratic_equilibrium(units.pressure_pu_to_density_lu(torch.tensor(0.01, dtype=dtype)),
@@ -556,11 +562,44 @@ def test_masked_two_step_launch_is_bit_identical_to_two_masked_single_steps(lat,
     f0, ncm, nsm, entries = _masked_case(lat, res, dtype, abb, 21, with_field=(seg == 3), abb_first=(seg == 2))
     plan = plan_for(lat, dtype, coll, res, entries)
     plan.set_masks(dev(ncm), dev(nsm))
+    _check_masked_two_step(plan, f0, abb is not None and abb != (0, 1), res, seg)
+
+
+MASKED_TWO_STEP_ROWS = [("D3Q19", [4, 8, 64], "f32", (2, 1)), ("D3Q19", [4, 8, 64], "f32", (2, -1)), ("D3Q19", [5, 16, 128], "f32", (2, 1)),
+                        ("D3Q19", [6, 16, 128], "f32", (2, -1)), ("D3Q27", [5, 4, 64], "f32", (2, 1)), ("D3Q27", [4, 8, 128], "f32", (2, -1)),
+                        ("D3Q15", [5, 8, 64], "f32", (2, 1)), ("D3Q15", [5, 8, 32], "f64", (2, 1)), ("D3Q15", [4, 16, 64], "f64", (2, -1))]
+
+
+@pytest.mark.parametrize("lat,res,dt,abb", MASKED_TWO_STEP_ROWS, ids=[f"{t[0]}-{'x'.join(map(str, t[1]))}-{t[2]}-{t[3]}" for t in MASKED_TWO_STEP_ROWS])
+@pytest.mark.parametrize("coll", ["bgk", "none"])
+@pytest.mark.parametrize("seg", [0, 2, 3])
+def test_masked_two_step_with_the_outlet_at_an_end_of_the_rows(lat, res, dt, abb, coll, seg):
+    """lbm2m_kernel, AX = 0: the anti-bounce-back outlet's normal is the contiguous axis (reference layout: z; in the
+    slab layout the Obstacle's x) and the face opposite it is an inlet of equilibrium nodes.  The node next to an
+    outlet node is the neighbouring lane; the outlet's no-streaming bits are a per-thread constant.  Bit for bit
+    two one-step launches; without the inlet face the plan is refused."""
+    dtype = TORCH_DT[dt]
+    f0, ncm, nsm, entries = _masked_case(lat, res, dtype, abb, 33, with_field=(seg == 3), abb_first=(seg == 2), inlet_face=True)
+    plan = plan_for(lat, dtype, coll, res, entries)
+    plan.set_masks(dev(ncm), dev(nsm))
+    _check_masked_two_step(plan, f0, False, res, seg)
+    if seg == 0 and coll == "bgk":
+        face = [slice(None)] * 3
+        face[abb[0]] = 0 if abb[1] == 1 else res[abb[0]] - 1
+        hole = ncm.clone()                                  # one fluid node in the inlet face
+        idx = [0, 0, 0]
+        idx[abb[0]] = face[abb[0]]
+        hole[tuple(idx)] = 0
+        plan.set_masks(dev(hole), dev(nsm))
+        _check_masked_two_step(plan, f0, True, res, seg)
+
+
+def _check_masked_two_step(plan, f0, refused, res, seg):
     f = dev(f0)
     a, b, c = torch.empty_like(f), torch.empty_like(f), torch.full_like(f, float("nan"))
+    plan.set_two_step(0)
     plan.stream_collide(f, a, 0.7)
     plan.stream_collide(a, b, 0.7)
-    refused = abb is not None and abb != (0, 1)
     if seg and res[0] % seg:
         seg = 2 if res[0] % 2 == 0 else 0
     plan.set_two_step(1, seg)
