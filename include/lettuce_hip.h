@@ -180,7 +180,14 @@ int lt_slab_unpack(lt_plan *plan, void *f_dev, int64_t plane, int32_t direction,
  *   buf[n_in_plane + 2 n_crossing][n1*n0] = [in-plane of the near plane | crossing of the near
  *   plane | crossing of the far plane]           (9 + 5 + 5 = 19 blocks for D3Q19);
  * lt_slab_unpack_two_step scatters a received message into the two ghost planes beyond `side`.
- * lt_slab_crossing(plan, 0, ...) reports the in-plane populations. */
+ * lt_slab_crossing(plan, 0, ...) reports the in-plane populations.
+ * Plans with masks (lt_plan_set_masks called) carry one more group of n_crossing blocks: the populations of
+ * the near plane that move away from the cut, which a no-streaming node of the ghost plane keeps (24 blocks
+ * for D3Q19); lt_slab_two_step_message_blocks reports the count.  With boundaries the two-step launches take
+ * bounce-back and equilibrium nodes and one anti-bounce-back outlet whose normal is x (the contiguous axis
+ * of the slab layout) opposite an inlet face of equilibrium nodes -- lt_plan_two_step_admitted returns
+ * LT_ERR_UNSUPPORTED with the reason otherwise; the fused packing of the entry points below exists for
+ * plans without masks only. */
 int lt_stream_collide_twice_planes(lt_plan *plan, const void *f_dev, void *out_dev, double tau,
                                    int64_t begin, int64_t end, void *stream);
 /* As lt_stream_collide_twice_planes, and in the same launch the halo message for the lower neighbour
@@ -195,6 +202,10 @@ int lt_stream_collide_twice_planes_packed(lt_plan *plan, const void *f_dev, void
 int lt_stream_collide_twice_edges(lt_plan *plan, const void *f_dev, void *out_dev, double tau,
                                   int32_t edge_planes, void *pack_lower_dev, void *pack_upper_dev,
                                   void *stream);
+int lt_slab_two_step_message_blocks(lt_plan *plan, int32_t *blocks_out);
+/* LT_OK when lt_stream_collide_twice / _planes has a kernel for this plan as it stands (lattice, dtype,
+ * collision, grid extents, masks); LT_ERR_UNSUPPORTED (and the reason in lt_last_error) otherwise. */
+int lt_plan_two_step_admitted(lt_plan *plan);
 int lt_slab_pack_two_step(lt_plan *plan, const void *f_dev, int32_t side, void *buf_dev, void *stream);
 int lt_slab_unpack_two_step(lt_plan *plan, void *f_dev, int32_t side, const void *buf_dev, void *stream);
 

@@ -97,6 +97,8 @@ SYMBOLS = {
     "lt_stream_collide_twice_planes": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _i64, _vp]),
     "lt_stream_collide_twice_planes_packed": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _i64, _vp, _vp, _vp]),
     "lt_stream_collide_twice_edges": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i32, _vp, _vp, _vp]),
+    "lt_slab_two_step_message_blocks": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
+    "lt_plan_two_step_admitted": (ctypes.c_int, [_vp]),
     "lt_slab_pack_two_step": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "lt_slab_unpack_two_step": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "lt_plan_set_fused_events": (ctypes.c_int, [_vp, _vp, _vp]),
@@ -546,6 +548,17 @@ class Plan:
             _stream_handle()))
 
     @_on_device
+    def two_step_message_blocks(self) -> int:
+        n = ctypes.c_int32(0)
+        self._check(self.lib.lt_slab_two_step_message_blocks(self._handle, ctypes.byref(n)))
+        return int(n.value)
+
+    def two_step_admitted(self) -> Optional[str]:
+        """None when the plan has a two-step launch; else the engine's reason"""
+        if self.lib.lt_plan_two_step_admitted(self._handle) == 0:
+            return None
+        return self.lib.lt_last_error().decode()
+
     def pack_two_step(self, f, side, buf):
         self._check(self.lib.lt_slab_pack_two_step(self._handle, _ptr(f), int(side), _ptr(buf), _stream_handle()))
 

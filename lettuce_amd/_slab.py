@@ -474,14 +474,19 @@ class SlabSimulation:
 
 class TwoStepSlabSimulation(SlabSimulation):
     """Slab driver for the two-step kernel (``lt_stream_collide_twice_planes``): two lattice updates
-    per launch and ONE halo exchange per two updates.  Periodic flows without boundaries; the
-    engine decides which lattices / dtypes / grids it supports (D3Q19 fp32, nx % 64 == 0,
-    ny % 8 == 0 at present) and raises otherwise.
+    per launch and ONE halo exchange per two updates.  The engine decides which lattices / dtypes /
+    grids it supports (nx % 64 == 0 in fp32, % 32 in fp64; ny % 8 == 0, D3Q27: % 4) and which
+    boundaries: bounce-back and equilibrium nodes anywhere and one anti-bounce-back outlet along x
+    opposite an inlet face of equilibrium nodes (the Obstacle); every rank asks its engine and all
+    ranks raise together when one of them has no two-step launch (use ``SlabSimulation`` then, as for
+    outlets along y or z).
 
     Two ghost planes per side.  Before a two-step launch the lower ghost planes must hold the
     in-plane and upward populations of the lower neighbour's top plane and the upward populations
     of the plane below it (mirrored above): 9 + 5 + 5 = 19 plane-populations per direction for
-    D3Q19 instead of 2 x 5 for two single steps, in half as many messages.
+    D3Q19 instead of 2 x 5 for two single steps, in half as many messages.  With boundaries the
+    message also carries the downward populations of that top plane (24 blocks): a node of the ghost
+    plane with no-streaming bits keeps them.
 
     Schedule of one double step: the communication stream computes the two output planes next to
     each cut (two small launches), packs, transfers and unpacks; the compute stream does the
@@ -505,8 +510,7 @@ class TwoStepSlabSimulation(SlabSimulation):
         else:
             self._fused_remote = bool(fused_remote_pack)
             self.ONE_STREAM_WINDOWS = bool(fused_remote_pack)
-        if flow.boundaries:
-            raise LettuceException("the two-step slab driver handles periodic flows only")
+        self._masked = bool(flow.boundaries)
         if slab.nz_local < 4:
             raise LettuceException("the two-step slab driver needs at least 4 planes per rank")
         # output planes per cut computed ahead of the interior (>= 2: the halo message reads two).
@@ -514,6 +518,16 @@ class TwoStepSlabSimulation(SlabSimulation):
         # 0.367 ms per step with peer windows -- no reason to delay the exchange.
         self.edge_planes = max(2, int(os.environ.get("LT_SLAB_EDGE_PLANES", "2")))
         super().__init__(flow, collision, slab, **kwargs)
+        # every rank must take the same path: agree on whether all engines have a two-step launch
+        why = self.engine.two_step_admitted() if hasattr(self.engine, "two_step_admitted") else None
+        refused = torch.tensor([0 if why is None else 1], dtype=torch.int32)
+        if slab.world_size > 1:
+            backend = dist.get_backend(self.group)
+            refused = refused.to(self.f.device if backend == "nccl" else "cpu")
+            dist.all_reduce(refused, op=dist.ReduceOp.MAX, group=self.group)
+        if int(refused.item()):
+            raise LettuceException("the two-step slab driver cannot run this flow"
+                                   + (f": {why}" if why else " (refused on another rank)"))
         # A two-step workgroup holds a CU's LDS for its whole segment, and RCCL's copy kernel needs
         # LDS of its own: beside one long interior segment per CU it starts only when the first
         # workgroups retire.  Shorter segments let it in earlier: a quarter of the interior planes
@@ -526,7 +540,7 @@ class TwoStepSlabSimulation(SlabSimulation):
 
     def _message_blocks(self, stencil) -> int:
         e = np.array(stencil.e)
-        return int((e[:, 2] == 0).sum()) + 2 * len(self.up)
+        return int((e[:, 2] == 0).sum()) + (3 if self._masked else 2) * len(self.up)
 
     # ---- halo exchange -------------------------------------------------------------------------
     def _exchange(self, buf: torch.Tensor, packed: bool = False):
@@ -580,11 +594,12 @@ class TwoStepSlabSimulation(SlabSimulation):
         # hold all CUs (one workgroup per CU, 150 KB of LDS) for that long, so a separate light pack
         # launch does them beside the interior launch instead (fused_remote_pack=True to A/B; on
         # one GPU, where the "remote" stores are local, fusing is 2 % faster; bench.py times both).
-        fuse = self._window is None or self._fused_remote
+        fuse = (self._window is None or self._fused_remote) and not self._masked   # fused packing: periodic plans
         # One launch for both edges (lt_stream_collide_twice_edges) measured no better (RCCL, fused
         # windows) or worse (separate pack on two streams: 0.389 vs 0.348 ms/step -- the bigger launch
         # competes with the interior launch for CUs and delays the exchange): two launches.
-        if hasattr(eng, "stream_collide_twice_edges") and os.environ.get("LT_SLAB_MERGED_EDGES") == "1":
+        if (hasattr(eng, "stream_collide_twice_edges") and os.environ.get("LT_SLAB_MERGED_EDGES") == "1"
+                and not self._masked):
             if fuse:
                 down, up = ((self._send_down, self._send_up) if self._window is None
                             else self._window.targets())

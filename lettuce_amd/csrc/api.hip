@@ -318,19 +318,21 @@ int halo2(lt_plan *p, bool do_pack, void *f, int side, void *buf, void *stream) 
     dir = -side;
   }
   const lt::QList in_plane = crossing(p, 0), cross = crossing(p, dir);
+  lt::QList away = crossing(p, -dir);
+  if (!p->masked) away.n = 0;                      // only a no-streaming node ever reads them
   const int plane_nodes = p->n0 * p->n1;
   const unsigned grid = (plane_nodes + lt::kThreads - 1) / lt::kThreads;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (p->desc.dtype == LT_F32) {
     if (do_pack) hipLaunchKernelGGL((lt::halo2_kernel<float, true>), dim3(grid), dim3(lt::kThreads), 0, s, (float *)f,
-                                    (float *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross);
+                                    (float *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross, away);
     else hipLaunchKernelGGL((lt::halo2_kernel<float, false>), dim3(grid), dim3(lt::kThreads), 0, s, (float *)f,
-                            (float *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross);
+                            (float *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross, away);
   } else {
     if (do_pack) hipLaunchKernelGGL((lt::halo2_kernel<double, true>), dim3(grid), dim3(lt::kThreads), 0, s, (double *)f,
-                                    (double *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross);
+                                    (double *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross, away);
     else hipLaunchKernelGGL((lt::halo2_kernel<double, false>), dim3(grid), dim3(lt::kThreads), 0, s, (double *)f,
-                            (double *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross);
+                            (double *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross, away);
   }
   LT_HIP(hipGetLastError());
   return LT_OK;
@@ -402,6 +404,13 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.masked = p->masked;
   a.abb_depth = p->n_abb > 1 ? p->n_abb - 1 : 0;
   a.abb_axis = p->masked ? masked_two_step_axis(p) : 2;
+  a.abb0_slot = 0;
+  if (p->masked && p->n_abb == 1)
+    for (int i = 0; i < p->desc.n_boundaries; ++i) {
+      const lt_boundary_desc &b = p->desc.boundaries[i];
+      if (b.kind == LT_BOUNDARY_ABB_OUTLET && !(b.flags & LT_BOUNDARY_ABSENT) && mem_axis_of(p, b.axis) == 0)
+        a.abb0_slot = i + 1;
+    }
   const bool aligned = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
   const bool hot = mode == lt::kFused && !a.masked && a.coll == LT_COLLISION_BGK;
   a.wide = (p->want_wide && hot && p->wide_ok && aligned) ? 1 : 0;
@@ -484,20 +493,41 @@ long long run_graph(lt_plan *p, void *cur, void *other, double tau, long long fu
   return reps * kGraphChunk;
 }
 
-// Does lt_run pair its fused steps?  Needs the two-step kernel for this lattice / dtype / collision
-// (asked of the unit by name), a grid that tiles (a0 % 64, a1 % 8) and no masks; "automatic" also
-// asks for the streaming regime (populations beyond the caches), where halving the HBM passes pays.
-bool two_step_wanted(lt_plan *p) {
-  if (p->two_step == 0 || p->desc.ghost_planes) return false;
-  if (p->masked && !masked_two_step_ok(p)) return false;
+// Is there a two-step launch for this plan?  Needs the kernel for this lattice / dtype / collision (asked of
+// the unit by name), a grid that tiles (a0 % 64, a1 % 8) and, with masks, their admission
+// (masked_two_step_axis).  why != nullptr: the reason it is not.
+bool two_step_possible(lt_plan *p, const char **why) {
+  const char *dummy;
+  if (!why) why = &dummy;
   const TwoStepTile tile = two_step_tile(p);
-  if (tile.rows == 0 || p->n0 % tile.width != 0 || p->n1 % tile.rows != 0) return false;
+  if (tile.rows == 0 || p->n0 % tile.width != 0 || p->n1 % tile.rows != 0) {
+    *why = "the grid does not tile (contiguous extent % 64 (fp32) / 32 (fp64), middle extent % 8 or 4)";
+    return false;
+  }
+  if (p->masked && (!masked_two_step_ok(p) || (p->desc.ghost_planes && p->n_abb > 0 && masked_two_step_axis(p) != 0))) {
+    *why = "boundaries: at most one anti-bounce-back outlet, at the last plane of the slowest memory axis (periodic "
+           "plans only) or at an end of the contiguous axis opposite a face of equilibrium nodes; no-streaming bits "
+           "exactly that outlet's";
+    return false;
+  }
   lt::StepArgs a;
   memset(&a, 0, sizeof a);
   a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = lt::kFusedTwice;
   a.masked = p->masked;
+  a.abb_axis = p->masked ? masked_two_step_axis(p) : 2;
   a.strip = p->unit.d == 2 ? tile.width : 0;
-  if (!p->unit.name(a)) return false;
+  if (!p->unit.name(a)) {
+    *why = "no two-step kernel for this lattice / dtype / collision";
+    return false;
+  }
+  return true;
+}
+
+// Does lt_run pair its fused steps?  "automatic" also asks for the streaming regime (populations beyond the
+// caches), where halving the HBM passes pays.
+bool two_step_wanted(lt_plan *p) {
+  if (p->two_step == 0 || p->desc.ghost_planes) return false;
+  if (!two_step_possible(p, nullptr)) return false;
   if (p->two_step == 1) return true;
   const long long bytes = 2ll * p->unit.q * p->N * p->esize;
   return bytes > (128ll << 20);
@@ -965,6 +995,17 @@ int lt_stream_collide_twice_edges(lt_plan *p, const void *f, void *out, double t
   p->seg_len = saved;
   p->second_begin = p->second_end = 0;
   return rc;
+}
+int lt_plan_two_step_admitted(lt_plan *p) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  const char *why = "";
+  if (!two_step_possible(p, &why)) return fail(LT_ERR_UNSUPPORTED, "two steps per launch: %s", why);
+  return LT_OK;
+}
+int lt_slab_two_step_message_blocks(lt_plan *p, int32_t *blocks) {
+  if (!p || !blocks) return fail(LT_ERR_INVALID, "null argument");
+  *blocks = crossing(p, 0).n + (p->masked ? 3 : 2) * crossing(p, 1).n;
+  return LT_OK;
 }
 int lt_slab_pack_two_step(lt_plan *p, const void *f, int32_t side, void *buf, void *s) {
   return halo2(p, true, const_cast<void *>(f), side, buf, s);

@@ -70,6 +70,10 @@ struct KParams {
   // [k][n1*n0], k = rank of q among the populations with that e (ascending q)
   T *pack_lo, *pack_hi;
   int pack_lo_plane, pack_hi_plane;
+  // one-step kernels: slot of the plan's only anti-bounce-back outlet when its normal is the contiguous axis
+  // and the rows are whole waves (n0 % 64 == 0): the node next to an outlet node then sits in the next lane
+  // (lbm_body); 0: none
+  int abb0_slot;
 };
 
 // ---- constants the reference builds from cs = 1/np.sqrt(3.0) (lettuce/_stencil.py:17) ----
@@ -577,13 +581,16 @@ __device__ __forceinline__ void lower_boundaries_on_moments(const KParams<T> &p,
   }
 }
 
-// AntiBounceBackOutlet (lettuce/ext/_boundary/anti_bounce_back_outlet.py:72-91) on one node
-// of the outlet plane, given (rho, j) of the node next to it (neighbour_moments).
-template <typename T, class S, int LAYOUT, int VEC, int k>
-__device__ __forceinline__ void abb_apply(const KParams<T> &p, int slot, T rn, const T (&jn)[3],
-                                          T (&f)[S::Q][VEC]) {
+// AntiBounceBackOutlet (lettuce/ext/_boundary/anti_bounce_back_outlet.py:72-91) on one node of the outlet
+// plane, whose normal is memory axis AX, given (rho, j) of the node next to it (neighbour_moments, or the
+// two-step kernels' saved / shuffled moments).  Only the populations leaving through the plane (e.n = +1)
+// are read and only their opposites written, so nothing is computed for the others.  No FMA contraction
+// here: the function is inlined into one-step and two-step kernels that must agree bit for bit, and which
+// products the backend fuses depends on the surrounding code (the reference's CPU ops do not fuse either).
+template <typename T, class S, int LAYOUT, int AX, int VEC = 1, int k = 0>
+__device__ __forceinline__ void abb_apply_ax(int side, T rn, const T (&jn)[3], T (&f)[S::Q][VEC]) {
+#pragma clang fp contract(off)
   using M = MemMap<S, LAYOUT>;
-  const int ax = p.bt->mem_axis[slot], side = p.bt->side[slot];
   T rho, j[3];
   moments<T, S, LAYOUT, VEC, k>(f, rho, j);
   T uw[3];
@@ -594,18 +601,25 @@ __device__ __forceinline__ void abb_apply(const KParams<T> &p, int slot, T rn, c
   }
   const T nrm = sqrt(uw[0] * uw[0] + uw[1] * uw[1] + uw[2] * uw[2]) / T(kCs);
   const T nrm2 = nrm * nrm;
-  T fresh[S::Q];
   static_for<S::Q>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
-    const int en = (ax == 0 ? M::e(q, 0) : (ax == 1 ? M::e(q, 1) : M::e(q, 2))) * side;
-    const T eu = dot_e<S, LAYOUT, q>(uw);
-    fresh[q] = en == 1 ? -f[q][k] + T(S::W[q]) * rho * (T(2) + eu * eu / T(kCs4) - nrm2) : T(0);
+    constexpr int en = AX < S::D ? M::e(q, AX) : 0;
+    if constexpr (en != 0) {
+      if (en * side == 1) {
+        const T eu = dot_e<S, LAYOUT, q>(uw);
+        f[S::OPP[q]][k] = -f[q][k] + T(S::W[q]) * rho * (T(2) + eu * eu / T(kCs4) - nrm2);
+      }
+    }
   });
-  static_for<S::Q>([&](auto qc) {
-    constexpr int q = decltype(qc)::value;
-    const int en = (ax == 0 ? M::e(q, 0) : (ax == 1 ? M::e(q, 1) : M::e(q, 2))) * side;
-    if (en == 1) f[S::OPP[q]][k] = fresh[q];
-  });
+}
+// the same for the outlet with index `slot` of the plan
+template <typename T, class S, int LAYOUT, int VEC, int k>
+__device__ __forceinline__ void abb_apply(const KParams<T> &p, int slot, T rn, const T (&jn)[3],
+                                          T (&f)[S::Q][VEC]) {
+  const int ax = p.bt->mem_axis[slot], side = p.bt->side[slot];
+  if (ax == 0) abb_apply_ax<T, S, LAYOUT, 0, VEC, k>(side, rn, jn, f);
+  else if (ax == 1) abb_apply_ax<T, S, LAYOUT, 1, VEC, k>(side, rn, jn, f);
+  else abb_apply_ax<T, S, LAYOUT, 2, VEC, k>(side, rn, jn, f);
 }
 
 // (rho, j) of the node (c0, c1, c2), as Flow.rho()/Flow.u() would see it when the AntiBounceBackOutlet with
@@ -684,9 +698,12 @@ __device__ __forceinline__ void abb_outlet(const KParams<T> &p, int slot, int c0
 
 // The boundaries of one node in index order (lettuce/_simulation.py:183-188); b = the node's index in
 // no_collision_mask, (c0k, c1, c2) its memory coordinates, ownk its index within a population.
+// lane_slot != 0: (lane_rho, lane_j) are the moments of the node next to this one along a0 as outlet `lane_slot`
+// sees them, handed over by the neighbouring lane (lbm_body) instead of being gathered again.
 template <typename T, class S, int LAYOUT, bool STREAM, int VEC, int k, int COLL = 0, int ABBD = 0>
 __device__ __forceinline__ void apply_boundaries(const KParams<T> &p, int b, int c0k, int c1, int c2,
-                                                 unsigned ownk, T (&f)[S::Q][VEC]) {
+                                                 unsigned ownk, T (&f)[S::Q][VEC], int lane_slot = 0,
+                                                 T lane_rho = T(1), const T *lane_j = nullptr) {
   for (int slot = 1; slot <= p.nb; ++slot) {
     const int kind = p.bt->kind[slot];
     if (kind == kAbbOutlet) {
@@ -695,8 +712,14 @@ __device__ __forceinline__ void apply_boundaries(const KParams<T> &p, int b, int
       // (anti_bounce_back_outlet.py:81-91, _simulation.py:186-188)
       const int ax = p.bt->mem_axis[slot];
       const int coord = ax == 0 ? c0k : (ax == 1 ? c1 : c2);
-      if (coord == p.bt->plane[slot])
-        abb_outlet<T, S, LAYOUT, STREAM, true, VEC, k, COLL, ABBD>(p, slot, c0k, c1, c2, f);
+      if (coord == p.bt->plane[slot]) {
+        if (slot == lane_slot) {
+          const T jn[3] = {lane_j[0], lane_j[1], lane_j[2]};
+          abb_apply<T, S, LAYOUT, VEC, k>(p, slot, lane_rho, jn, f);
+        } else {
+          abb_outlet<T, S, LAYOUT, STREAM, true, VEC, k, COLL, ABBD>(p, slot, c0k, c1, c2, f);
+        }
+      }
     } else if (b == slot) {
       if (kind == kBounceBack) {
         bounce_back<T, S, VEC, k>(f);
@@ -760,6 +783,28 @@ __device__ __forceinline__ void lbm_body(const KParams<T> &p) {
     }
   }
 
+  // An outlet whose normal is the contiguous axis: the node next to an outlet node is held by the next lane of
+  // the same wave (rows are whole waves), whose populations at this point -- pulled, no-streaming slots kept,
+  // not yet collided -- are exactly what neighbour_moments would gather again (19-27 single-lane loads and
+  // their latency in every wave that ends a row: 0.48 -> 0.60 ms at 512 x 512 x 64 with the Obstacle's outlet)
+  int lane_slot = 0;
+  T lane_rho = T(1), lane_j[3] = {T(0), T(0), T(0)};
+  if constexpr (COLLIDE && MASKED && VEC == 1 && ABBD == 0) {
+    if (p.abb0_slot != 0) {
+      const int slot = p.abb0_slot, plane = p.bt->plane[slot];
+      const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      const int first = c0 - lane;                                 // a0 coordinate of lane 0: same in all lanes
+      if (plane >= first && plane < first + 64) {
+        moments<T, S, LAYOUT, 1, 0>(f, lane_rho, lane_j);
+        lower_boundaries_on_moments<T, S, LAYOUT>(p, nd[0] & 0x7f, slot, own, lane_rho, lane_j);
+        const int from = (lane - p.bt->side[slot]) & 63;
+        lane_rho = __shfl(lane_rho, from);
+        lane_j[0] = __shfl(lane_j[0], from); lane_j[1] = __shfl(lane_j[1], from); lane_j[2] = __shfl(lane_j[2], from);
+        lane_slot = slot;
+      }
+    }
+  }
+
   if constexpr (COLLIDE) {
     static_for<VEC>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
@@ -770,7 +815,8 @@ __device__ __forceinline__ void lbm_body(const KParams<T> &p) {
         if constexpr (COLL == 2) collide_kbc<T, S, LAYOUT, VEC, k>(f, p.beta, p.inv_beta);
       }
       if constexpr (MASKED)
-        apply_boundaries<T, S, LAYOUT, STREAM, VEC, k, COLL, ABBD>(p, b, c0 + k, c1, c2, own + k, f);
+        apply_boundaries<T, S, LAYOUT, STREAM, VEC, k, COLL, ABBD>(p, b, c0 + k, c1, c2, own + k, f, lane_slot,
+                                                                    lane_rho, lane_j);
     });
   }
 
@@ -1391,12 +1437,13 @@ __global__ void __launch_bounds__(kThreads) plane_pack_kernel(T *__restrict__ f,
 }
 
 // Halo message of the two-step slab driver: [in-plane populations of the plane next to the cut |
-// crossing populations of that plane | crossing populations of the plane behind it], each a
-// contiguous block of plane_nodes values.  PACK: f -> buf, else buf -> f.
+// crossing populations of that plane | crossing populations of the plane behind it | plans with masks: the
+// populations of the near plane that move AWAY from the cut, which a no-streaming node of the ghost plane
+// keeps], each a contiguous block of plane_nodes values.  PACK: f -> buf, else buf -> f.
 template <typename T, bool PACK>
 __global__ void __launch_bounds__(kThreads) halo2_kernel(T *__restrict__ f, T *__restrict__ buf, long long N,
                                                          long long off_near, long long off_far,
-                                                         int plane_nodes, QList in_plane, QList cross) {
+                                                         int plane_nodes, QList in_plane, QList cross, QList away) {
   const int i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= plane_nodes) return;
   auto move = [&](int slot, int q, long long off) {
@@ -1411,6 +1458,7 @@ __global__ void __launch_bounds__(kThreads) halo2_kernel(T *__restrict__ f, T *_
       move(in_plane.n + k, cross.q[k], off_near);
       move(in_plane.n + cross.n + k, cross.q[k], off_far);
     }
+    if (k < away.n) move(in_plane.n + 2 * cross.n + k, away.q[k], off_near);
   }
 }
 

@@ -68,59 +68,40 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t field_rsrc(const T *field, uns
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(field), 0, (int)bytes, 0x00020000);
 }
 
-// LDS bytes of lbm2m_kernel: 4 slots of the upward, 3 of the in-plane, 3 of the downward populations
+// LDS bytes of lbm2m_kernel: 4 slots of the upward, 3 of the in-plane, 3 of the downward populations, and the
+// populations of two uniform equilibrium boundaries
+constexpr int kEqCached = 2;
 template <typename T, class S, int LAYOUT, int T0, int T1>
 constexpr size_t two_step_masked_lds() {
   using B = TwoStep<T, S, T0, T1>;
-  return sizeof(T) * (size_t)B::NI *
-         (4 * B::template count<LAYOUT, 1>() + 3 * B::template count<LAYOUT, 0>() + 3 * B::template count<LAYOUT, -1>());
+  return sizeof(T) * ((size_t)B::NI * (4 * B::template count<LAYOUT, 1>() + 3 * B::template count<LAYOUT, 0>() +
+                                       3 * B::template count<LAYOUT, -1>()) + (size_t)kEqCached * S::Q);
 }
 
 // kinds of the plan's boundaries, two bits per slot, and the outlet's slot / plane (slot 0: no outlet)
 struct MaskedPlanInfo {
   unsigned kinds;
+  unsigned fields;                  // bit s: equilibrium boundary s has a per-node field
+  int eq_cached[kEqCached];         // the first uniform equilibrium boundaries: their populations sit in LDS (0: none)
   int abb_slot, abb_side, abb_plane, abb_axis;
 };
 template <typename T>
 __device__ __forceinline__ MaskedPlanInfo masked_plan_info(const KParams<T> &p) {
-  MaskedPlanInfo m = {0u, 0, 1, -1, 2};
+  MaskedPlanInfo m = {0u, 0u, {0, 0}, 0, 1, -1, 2};
+  int cached = 0;
   for (int slot = 1; slot <= p.nb; ++slot) {
     const int kind = p.bt->kind[slot];
     m.kinds |= (unsigned)kind << (2 * slot);
+    if (kind == kEquilibrium) {
+      if (p.bt->field[slot]) m.fields |= 1u << slot;
+      else if (cached < kEqCached) m.eq_cached[cached++] = slot;
+    }
     if (kind == kAbbOutlet) {
       m.abb_slot = slot; m.abb_side = p.bt->side[slot]; m.abb_plane = p.bt->plane[slot];
       m.abb_axis = p.bt->mem_axis[slot];
     }
   }
   return m;
-}
-
-// AntiBounceBackOutlet with its normal along memory axis AX (anti_bounce_back_outlet.py:72-91), given
-// (rho, j) of the node next to the plane; the arithmetic of abb_apply (kernels.hpp), operation for operation
-template <typename T, class S, int LAYOUT, int AX>
-__device__ __forceinline__ void abb_apply_ax(int side, T rn, const T (&jn)[3], T (&f)[S::Q][1]) {
-  using M = MemMap<S, LAYOUT>;
-  T rho, j[3];
-  moments<T, S, LAYOUT, 1, 0>(f, rho, j);
-  T uw[3];
-#pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    const T u = j[m] / rho, un = jn[m] / rn;
-    uw[m] = u + T(0.5) * (u - un);
-  }
-  const T nrm = sqrt(uw[0] * uw[0] + uw[1] * uw[1] + uw[2] * uw[2]) / T(kCs);
-  const T nrm2 = nrm * nrm;
-  // the populations leaving through the plane (e.n = +1) are only read, their opposites only written
-  static_for<S::Q>([&](auto qc) {
-    constexpr int q = decltype(qc)::value;
-    constexpr int en = M::e(q, AX);
-    if constexpr (en != 0) {
-      if (en * side == 1) {
-        const T eu = dot_e<S, LAYOUT, q>(uw);
-        f[S::OPP[q]][0] = -f[q][0] + T(S::W[q]) * rho * (T(2) + eu * eu / T(kCs4) - nrm2);
-      }
-    }
-  });
 }
 
 // AX: memory axis of the outlet's normal, 2 or 0 (plans without an outlet run the AX = 2 kernel)
@@ -138,6 +119,11 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   __shared__ T lds_u[4][NU][NI];
   __shared__ T lds_c[3][NC][NI];
   __shared__ T lds_d[3][ND][NI];
+  // A uniform equilibrium boundary writes the same Q values on each of its nodes.  Read from the plan's table
+  // in global memory they are a dependent load in the middle of every plane whose tile touches the boundary
+  // -- with an inlet FACE along the rows (slab layout) that is every plane of an eighth of the workgroups,
+  // measured 0.30 -> 0.41 ms per update at 512 x 512 x 64: the first two such boundaries are kept in LDS.
+  __shared__ T lds_feq[kEqCached][S::Q];
 
   const int tid = threadIdx.x;
   const int tiles0 = p.n0 / T0, tiles1 = p.n1 / T1;
@@ -152,6 +138,11 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   const bool in_a = tid < NI;
   const unsigned pop_bytes = (unsigned)(p.N * (long long)sizeof(T));
   const MaskedPlanInfo info = masked_plan_info(p);
+  if (tid < kEqCached * S::Q) {
+    const int c = tid / S::Q, slot = info.eq_cached[c];
+    lds_feq[c][tid - c * S::Q] = slot ? p.bt->feq[slot][tid - c * S::Q] : T(0);
+  }
+  lds_barrier();
   // AX = 0: is this thread's intermediate (a_out) / output (b_out) node on the outlet?  tile_out (uniform):
   // does the tile hold the outlet column among its inner columns?
   bool a_out = false, b_out = false;
@@ -218,11 +209,24 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
       if (kind == kBounceBack) {
         bounce_back<T, S, 1, 0>(g);
       } else if (kind == kEquilibrium) {
-        const T *fld = p.bt->field[bidx];
-        static_for<S::Q>([&](auto qc) {
-          constexpr int q = decltype(qc)::value;
-          g[q][0] = fld ? fld[(long long)q * p.N + own] : p.bt->feq[bidx][q];
-        });
+        if ((info.fields >> bidx) & 1u) {
+          const T *fld = p.bt->field[bidx];
+          static_for<S::Q>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            g[q][0] = fld[(long long)q * p.N + own];
+          });
+        } else if (bidx == info.eq_cached[0] || bidx == info.eq_cached[1]) {
+          const int c = bidx == info.eq_cached[0] ? 0 : 1;
+          static_for<S::Q>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            g[q][0] = lds_feq[c][q];
+          });
+        } else {
+          static_for<S::Q>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            g[q][0] = p.bt->feq[bidx][q];
+          });
+        }
       }
       if (on_outlet && info.abb_slot > bidx) abb_apply_ax<T, S, LAYOUT, AX>(info.abb_side, rn, jn, g);
     }

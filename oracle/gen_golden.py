@@ -421,6 +421,11 @@ if __name__ == "__main__":
                   4.0, (1.3, 1.6, 12.0), 0.7)
     obstacle_case("obstacle3d_d3q19_bgk_10x8x32_f64", [10, 8, 32], lt.D3Q19(), "f64", "bgk", {1, 2, 3, 8},
                   4.0, (1.3, 1.6, 6.0), 0.7)
+    # ... and on grids the slab layout's tiles take (x contiguous: two-step slab driver with boundaries)
+    obstacle_case("obstacle3d_d3q19_bgk_64x8x16_f32", [64, 8, 16], lt.D3Q19(), "f32", "bgk", {1, 2, 3, 8},
+                  4.0, (1.3, 0.25, 0.5), 0.2)
+    obstacle_case("obstacle3d_d3q27_bgk_64x8x16_f32", [64, 8, 16], lt.D3Q27(), "f32", "bgk", {1, 2, 3, 8},
+                  4.0, (1.3, 0.25, 0.5), 0.2)
     two_outlets_case("two_outlets_d2q9_bgk_f64", [12, 10], lt.D2Q9(), "f64")
     two_outlets_case("two_outlets_d3q19_bgk_f64", [8, 7, 6], lt.D3Q19(), "f64")
     two_outlets_case("two_outlets_d3q19_bgk_f32", [8, 7, 6], lt.D3Q19(), "f32")

@@ -122,11 +122,23 @@ class OracleSlabEngine:
         return ([q for q in range(self.lat.q) if ez[q] == 0],
                 [q for q in range(self.lat.q) if ez[q] == direction])
 
+    def two_step_admitted(self):
+        """the HIP engine's rule for boundaries (lt_plan_two_step_admitted): outlets along x only"""
+        for b in self.entries:
+            if b["kind"] == "abb_outlet" and b["axis"] != 0:
+                return "anti-bounce-back outlet along y or z"
+        return None
+
     def pack_two_step(self, f, side, buf):
+        """[in-plane of the near plane | crossing of the near plane | crossing of the far plane | with masks: the
+        populations of the near plane moving away from the cut] (include/lettuce_hip.h, lt_slab_pack_two_step)"""
         n2 = f.shape[1]
         near, far = (2, 3) if side < 0 else (n2 - 3, n2 - 4)
         in_plane, cross = self._sets(side)
-        buf.copy_(torch.cat([f[in_plane, near], f[cross, near], f[cross, far]]))
+        parts = [f[in_plane, near], f[cross, near], f[cross, far]]
+        if self.ncm is not None:
+            parts.append(f[self._sets(-side)[1], near])
+        buf.copy_(torch.cat(parts))
 
     def unpack_two_step(self, f, side, buf):
         n2 = f.shape[1]
@@ -135,4 +147,6 @@ class OracleSlabEngine:
         a, b = len(in_plane), len(cross)
         f[in_plane, near] = buf[:a]
         f[cross, near] = buf[a:a + b]
-        f[cross, far] = buf[a + b:]
+        f[cross, far] = buf[a + b:a + 2 * b]
+        if self.ncm is not None:
+            f[self._sets(side)[1], near] = buf[a + 2 * b:]

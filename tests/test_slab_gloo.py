@@ -117,7 +117,7 @@ def test_single_rank_slab_self_exchange():
     np.testing.assert_allclose(sim.gather_f().numpy(), ref.f.numpy(), rtol=0, atol=1e-13)
 
 
-def _obstacle_worker(rank, world, port, name, steps, out_dir):
+def _obstacle_worker(rank, world, port, name, steps, out_dir, driver="SlabSimulation"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
@@ -133,7 +133,7 @@ def _obstacle_worker(rank, world, port, name, steps, out_dir):
                        stencil=lt.D3Q27(), slab=slab)
     flow.mask = torch.tensor(g["obstacle_mask"])[:, :, slab.z_indices()]
     flow.initialize()
-    sim = lt.SlabSimulation(flow, lt.KBCCollision(), slab, engine=OracleSlabEngine("D3Q27", torch.float64, "kbc"))
+    sim = getattr(lt, driver)(flow, lt.KBCCollision(), slab, engine=OracleSlabEngine("D3Q27", torch.float64, "kbc"))
     f0 = sim.gather_f()
     sim(steps)
     f1 = sim.gather_f()
@@ -143,14 +143,17 @@ def _obstacle_worker(rank, world, port, name, steps, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_slab_ranks_with_obstacle_boundaries(tmp_path, world):
+@pytest.mark.parametrize("world,driver", [(2, "SlabSimulation"), (3, "SlabSimulation"), (2, "TwoStepSlabSimulation"),
+                                          (3, "TwoStepSlabSimulation")])
+def test_slab_ranks_with_obstacle_boundaries(tmp_path, world, driver):
     """Obstacle (equilibrium inlet, ABB outlet along x, sphere bounce-back) on z-slabs: masks are
-    built per rank on its planes of the global grid and the result equals the reference's."""
+    built per rank on its planes of the global grid and the result equals the reference's -- with one
+    exchange per step and with the two-step driver (two ghost planes, one 36-block message per double step:
+    with boundaries it also carries the populations a no-streaming node of the ghost plane keeps)."""
     from conftest import golden
     name, steps = "obstacle3d_d3q27_kbc_f64", 8
-    port = 29300 + (os.getpid() % 2000) + world
-    mp.spawn(_obstacle_worker, args=(world, port, name, steps, str(tmp_path)), nprocs=world, join=True)
+    port = 29300 + (os.getpid() % 2000) + world + (10 if driver != "SlabSimulation" else 0)
+    mp.spawn(_obstacle_worker, args=(world, port, name, steps, str(tmp_path), driver), nprocs=world, join=True)
     g, got = golden(name), np.load(tmp_path / "out.npz")
     np.testing.assert_allclose(got["f0"], g["f0"], rtol=0, atol=1e-15)
     np.testing.assert_allclose(got["f1"], g["f8"], rtol=0, atol=1e-12)
@@ -295,6 +298,36 @@ def _z_channel(lt, ctx, res, slab=None):
             return [lt.EquilibriumBoundaryPU(self.context, gz == 0, [0.0, 0.0, 0.05]),
                     lt.AntiBounceBackOutlet([0, 0, 1], self), lt.BounceBackBoundary(block)]
     return Channel(ctx, slab.extended_resolution if slab is not None else res, 100, 0.05, lt.D3Q19(), slab=slab)
+
+
+def _z_channel_two_step_worker(rank, world, port, res, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lettuce_amd as lt
+    from slab_cpu_engine import OracleSlabEngine
+    ctx = lt.Context("cpu", torch.float64, use_native=False)
+    slab = lt.ZSlab(res)
+    flow = _z_channel(lt, ctx, res, slab)
+    refused = ""
+    try:
+        lt.TwoStepSlabSimulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
+                                 engine=OracleSlabEngine("D3Q19", torch.float64, "bgk"))
+    except lt.LettuceException as e:
+        refused = str(e)
+    with open(os.path.join(out_dir, f"refused{rank}.txt"), "w") as fh:
+        fh.write(refused)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_step_slab_driver_refuses_an_outlet_along_z_on_every_rank(tmp_path):
+    """The two-step launches take outlets along x only; the ranks agree (all-reduce) before any of them steps, so
+    no rank is left waiting in an exchange for one that raised."""
+    mp.spawn(_z_channel_two_step_worker, args=(2, 29950 + os.getpid() % 2000, [6, 5, 12], str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        assert "two-step slab driver cannot run this flow" in (tmp_path / f"refused{rank}.txt").read_text()
 
 
 def _z_channel_worker(rank, world, port, res, steps, out_dir):
