@@ -88,7 +88,13 @@ def test_cfg1_anchor_energies():
 OBST = [("obstacle2d_d2q9_bgk_f64", "D2Q9", "bgk", "f64", (1, 2, 10)),
         ("obstacle3d_d3q27_kbc_f64", "D3Q27", "kbc", "f64", (1, 2, 8)),
         ("obstacle3d_d3q27_kbc_f32", "D3Q27", "kbc", "f32", (2, 8)),
-        ("obstacle3d_d3q19_bgk_f64", "D3Q19", "bgk", "f64", (2, 8))]
+        ("obstacle3d_d3q19_bgk_f64", "D3Q19", "bgk", "f64", (2, 8)),
+        # the grids the two-step kernels' tiles take (reference layout: z % 64; slab layout: x % 64)
+        ("obstacle3d_d3q19_bgk_12x16x64_f32", "D3Q19", "bgk", "f32", (1, 2, 3, 8)),
+        ("obstacle3d_d3q27_bgk_10x8x64_f32", "D3Q27", "bgk", "f32", (1, 2, 3, 8)),
+        ("obstacle3d_d3q19_bgk_10x8x32_f64", "D3Q19", "bgk", "f64", (1, 2, 3, 8)),
+        ("obstacle3d_d3q19_bgk_64x8x16_f32", "D3Q19", "bgk", "f32", (1, 2, 3, 8)),
+        ("obstacle3d_d3q27_bgk_64x8x16_f32", "D3Q27", "bgk", "f32", (1, 2, 3, 8))]
 
 
 def obstacle_oracle(g, lat_name, coll, dt):
