@@ -289,9 +289,11 @@ def main():
             coll = lt.BGKCollision(flow.units.relaxation_parameter_lu)
             if driver == "two-step":
                 # "window-fused": edge launches store into the neighbour's window themselves, one stream
+                # "rccl-signalled": one launch per double step whose edge workgroups run first and release the exchange
                 return lt.TwoStepSlabSimulation(flow, coll, slab, overlap=not args.no_overlap,
                                                 transport=transport.split("-")[0],
-                                                fused_remote_pack=transport.endswith("-fused"))
+                                                fused_remote_pack=transport.endswith("-fused"),
+                                                signalled=transport.endswith("-signalled"))
             return lt.SlabSimulation(flow, coll, slab, overlap=not args.no_overlap, transport=transport)
 
         def all_ranks(flag: bool) -> bool:
@@ -308,6 +310,8 @@ def main():
         transports = {"auto": ["rccl"], "all": ["rccl", "window"]}.get(args.transport, [args.transport])
         drivers = ["two-step", "single-step"] if args.driver == "auto" else [args.driver]
         wanted = [(d, t) for d in drivers for t in transports]
+        if "two-step" in drivers and "rccl" in transports and not args.no_overlap:
+            wanted.insert(wanted.index(("two-step", "rccl")) + 1, ("two-step", "rccl-signalled"))
         if "two-step" in drivers and "window" in transports:
             wanted.insert(wanted.index(("two-step", "window")) + 1, ("two-step", "window-fused"))
         if args.driver == "auto" and args.transport in ("auto", "all"):
@@ -385,6 +389,8 @@ def main():
         kernel = sim.engine.kernel_name()
         step = sim
         how = ("RCCL send/recv ghost planes" if transport == "rccl"
+               else "RCCL send/recv ghost planes, released by the edge workgroups of the one launch per double step"
+               if transport == "rccl-signalled"
                else "one-sided ghost-plane stores into peer windows (xGMI peer access)"
                + (", issued by the edge launches" if transport.endswith("-fused") else ""))
         how += ("; two lattice updates per launch, one exchange per two updates" if driver == "two-step"

@@ -202,6 +202,17 @@ int lt_stream_collide_twice_planes_packed(lt_plan *plan, const void *f_dev, void
 int lt_stream_collide_twice_edges(lt_plan *plan, const void *f_dev, void *out_dev, double tau,
                                   int32_t edge_planes, void *pack_lower_dev, void *pack_upper_dev,
                                   void *stream);
+/* The whole slab -- output planes [2, n2 - 2) -- in ONE launch that releases the exchange while it runs (plans
+ * without masks).  The workgroups that produce the two planes next to each cut start first; each adds 1 to a
+ * counter of the plan when those planes are in memory.  lt_slab_wait_edges enqueues, on ANOTHER stream, one
+ * polling wave that returns when the counter has reached the value that completes the edges of the last such
+ * launch -- work enqueued behind it (lt_slab_pack_two_step, the transfers, lt_slab_unpack_two_step) then runs
+ * beside the rest of the sweep -- or after about one second (lt_slab_wait_timed_out then reports 1; it
+ * synchronises the stream).  Replaces two edge launches + one interior launch: no planes are computed twice at
+ * the lower cut, the upper edge costs its prologue only once, and three launches do not compete for the CUs. */
+int lt_stream_collide_twice_slab(lt_plan *plan, const void *f_dev, void *out_dev, double tau, void *stream);
+int lt_slab_wait_edges(lt_plan *plan, void *stream);
+int lt_slab_wait_timed_out(lt_plan *plan, int32_t *timed_out, void *stream);
 int lt_slab_two_step_message_blocks(lt_plan *plan, int32_t *blocks_out);
 /* LT_OK when lt_stream_collide_twice / _planes has a kernel for this plan as it stands (lattice, dtype,
  * collision, grid extents, masks); LT_ERR_UNSUPPORTED (and the reason in lt_last_error) otherwise. */

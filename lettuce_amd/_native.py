@@ -97,6 +97,9 @@ SYMBOLS = {
     "lt_stream_collide_twice_planes": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _i64, _vp]),
     "lt_stream_collide_twice_planes_packed": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _i64, _vp, _vp, _vp]),
     "lt_stream_collide_twice_edges": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i32, _vp, _vp, _vp]),
+    "lt_stream_collide_twice_slab": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _vp]),
+    "lt_slab_wait_edges": (ctypes.c_int, [_vp, _vp]),
+    "lt_slab_wait_timed_out": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _vp]),
     "lt_slab_two_step_message_blocks": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
     "lt_plan_two_step_admitted": (ctypes.c_int, [_vp]),
     "lt_slab_pack_two_step": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
@@ -548,6 +551,19 @@ class Plan:
             _stream_handle()))
 
     @_on_device
+    def stream_collide_twice_slab(self, f, out, tau):
+        """all interior planes in one launch whose edge workgroups run first and count themselves done on a
+        device counter (``wait_edges`` on another stream waits for it)"""
+        self._check(self.lib.lt_stream_collide_twice_slab(self._handle, _ptr(f), _ptr(out), float(tau), _stream_handle()))
+
+    def wait_edges(self):
+        self._check(self.lib.lt_slab_wait_edges(self._handle, _stream_handle()))
+
+    def wait_timed_out(self) -> bool:
+        flag = ctypes.c_int32(0)
+        self._check(self.lib.lt_slab_wait_timed_out(self._handle, ctypes.byref(flag), _stream_handle()))
+        return bool(flag.value)
+
     def two_step_message_blocks(self) -> int:
         n = ctypes.c_int32(0)
         self._check(self.lib.lt_slab_two_step_message_blocks(self._handle, ctypes.byref(n)))

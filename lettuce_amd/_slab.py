@@ -96,6 +96,7 @@ def _comm_stream(device, priority):
     pooled streams round-robin and HIP maps them onto a few hardware queues; a fresh stream per
     simulation made some instances 30-45 % slower than others in the same process (the boundary /
     exchange work no longer overlapped the interior launch), see tools/slab_history_probe.py."""
+    priority = int(os.environ.get("LT_SLAB_COMM_PRIORITY", priority))
     key = (str(device), int(priority))
     if key not in _COMM_STREAMS:
         _COMM_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
@@ -499,11 +500,22 @@ class TwoStepSlabSimulation(SlabSimulation):
     # launch takes as long as the transfer and would delay the interior launch: two streams.
     ONE_STREAM_WINDOWS = False
 
-    def __init__(self, flow, collision, slab: ZSlab, fused_remote_pack: Optional[bool] = None, **kwargs):
+    def __init__(self, flow, collision, slab: ZSlab, fused_remote_pack: Optional[bool] = None,
+                 signalled: Optional[bool] = None, **kwargs):
         """``fused_remote_pack`` (window transport only): True = the edge launches store the halo
         message into the neighbour's window themselves and the whole exchange rides on the compute
         stream; False (default, see ``_edges``) = a separate pack launch on the communication
-        stream.  None reads LT_SLAB_FUSED_REMOTE_PACK / LT_SLAB_ONE_STREAM."""
+        stream.  None reads LT_SLAB_FUSED_REMOTE_PACK / LT_SLAB_ONE_STREAM.
+
+        ``signalled`` (RCCL transport, periodic flows, HIP engine): True = ONE launch per double step
+        covers all interior planes; its edge workgroups start first and count themselves done on a device
+        counter, and the communication stream -- one polling wave, then the pack launches, the transfers
+        and the unpack launches -- works beside the rest of the sweep
+        (``lt_stream_collide_twice_slab``).  Saves the two edge launches (planes computed twice, launches
+        competing with the interior one).  None reads LT_SLAB_SIGNALLED (default off)."""
+        if signalled is None:
+            signalled = os.environ.get("LT_SLAB_SIGNALLED") == "1"
+        self._signalled = bool(signalled)
         if fused_remote_pack is None:
             self._fused_remote = os.environ.get("LT_SLAB_FUSED_REMOTE_PACK") == "1"
             self.ONE_STREAM_WINDOWS = os.environ.get("LT_SLAB_ONE_STREAM") == "1"
@@ -534,6 +546,8 @@ class TwoStepSlabSimulation(SlabSimulation):
         # (15 of 60) measured 0.357 vs 0.369 ms/step in the self-exchange rehearsal, 10 and 6 planes
         # are slower again (0.371, 0.392); LT_SLAB_RCCL_SEGMENT overrides, 0 = the engine's choice.
         interior = self.hi - self.lo - 2 * self.edge_planes
+        if self._signalled:
+            interior = -(-(self.hi - self.lo - 2) // 4) * 4     # the one launch sweeps all planes but the upper edge
         seg = int(os.environ.get("LT_SLAB_RCCL_SEGMENT", str(interior // 4 if interior >= 32 else 0)))
         if seg > 0 and self._window is None and hasattr(self.engine, "set_two_step"):
             self.engine.set_two_step(1, seg)
@@ -617,9 +631,21 @@ class TwoStepSlabSimulation(SlabSimulation):
         eng.stream_collide_twice_planes(cur, nxt, tau, hi - edge, hi)
         return False
 
+    def _signalled_ok(self) -> bool:
+        return (self._signalled and self.overlap and self._window is None and not self._masked
+                and hasattr(self.engine, "stream_collide_twice_slab"))
+
     def _double_step(self, cur, nxt, tau):
         eng, lo, hi = self.engine, self.lo, self.hi
         edge = self.edge_planes
+        if self._signalled_ok():
+            # one launch; the communication stream waits for the edge workgroups' count, not for the launch
+            eng.stream_collide_twice_slab(cur, nxt, tau)
+            with torch.cuda.stream(self._comm):
+                eng.wait_edges()
+                self._exchange(nxt)()
+            torch.cuda.current_stream().wait_stream(self._comm)
+            return
         if self._one_stream and hi - lo >= 2 * edge + 4:
             packed = self._edges(cur, nxt, tau)
             finish = self._exchange(nxt, packed)  # (pack into the neighbours' windows) + signal

@@ -98,6 +98,12 @@ struct lt_plan {
   int nsm_confined = 1;      // the no-streaming bits are exactly those of the plan's outlet (lt_plan_set_masks)
   int inlet_faces_outlet = 1;  // outlet along a0: every node of the opposite face is an equilibrium node
   unsigned *mask_flag = nullptr;   // device word written by the mask compilation
+  // lt_stream_collide_twice_slab: counter the edge workgroups increment, the value it reaches when the messages
+  // of the last such launch are complete, and the word wait_counter_kernel sets when it gives up
+  unsigned long long *signal = nullptr;
+  unsigned long long signal_target = 0;
+  unsigned *signal_timed_out = nullptr;
+  unsigned long long *signal_now = nullptr;   // where step() finds the counter for the launch being issued (or null)
   char kernel_name[192];
   // launch-bound grids: a captured hipGraph of kGraphChunk fused steps (ping-pong returns to the
   // starting buffer), replayed on a plan-owned stream that is forked from / joined to the caller's
@@ -423,6 +429,7 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   if (mode == lt::kFusedMany) a.seg_len = p->many_now;
   a.stream = static_cast<hipStream_t>(stream);
   a.pack_lo = pack_lo; a.pack_hi = pack_hi;
+  a.signal = p->signal_now;
   a.pack_lo_plane = (int)pb; a.pack_hi_plane = (int)(pb + stride * (a.planes - 1));
   if (mode == lt::kFusedTwice) {
     a.p_begin2 = (int)p->second_begin;
@@ -722,6 +729,8 @@ int lt_plan_destroy(lt_plan *p) {
   if (p->nsm_bits) (void)hipFree(p->nsm_bits);
   if (p->bt) (void)hipFree(p->bt);
   if (p->mask_flag) (void)hipFree(p->mask_flag);
+  if (p->signal) (void)hipFree(p->signal);
+  if (p->signal_timed_out) (void)hipFree(p->signal_timed_out);
   if (p->partial) (void)hipFree(p->partial);
   if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
   if (p->gev_in) (void)hipEventDestroy(p->gev_in);
@@ -995,6 +1004,60 @@ int lt_stream_collide_twice_edges(lt_plan *p, const void *f, void *out, double t
   p->seg_len = saved;
   p->second_begin = p->second_end = 0;
   return rc;
+}
+// The whole slab in one launch that feeds the exchange while it runs: see include/lettuce_hip.h
+int lt_stream_collide_twice_slab(lt_plan *p, const void *f, void *out, double tau, void *stream) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (p->desc.ghost_planes != 2) return fail(LT_ERR_INVALID, "the two-step slab launch needs ghost_planes = 2");
+  if (p->masked) return fail(LT_ERR_UNSUPPORTED, "the signalling slab launch exists for plans without masks");
+  const long long lo = 2, hi = p->n2 - 2;
+  if (hi - lo < 4) return fail(LT_ERR_INVALID, "the slab needs at least 4 interior planes");
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  if (!p->signal) {
+    LT_HIP(hipMalloc((void **)&p->signal, sizeof(unsigned long long)));
+    LT_HIP(hipMalloc((void **)&p->signal_timed_out, sizeof(unsigned)));
+    LT_HIP(hipMemsetAsync(p->signal, 0, sizeof(unsigned long long), hs));
+    LT_HIP(hipMemsetAsync(p->signal_timed_out, 0, sizeof(unsigned), hs));
+    p->signal_target = 0;
+  }
+  const TwoStepTile tile = two_step_tile(p);
+  if (tile.rows == 0 || p->n0 % tile.width != 0 || p->n1 % tile.rows != 0)
+    return fail(LT_ERR_UNSUPPORTED, "two steps per launch: the grid does not tile");
+  // upper edge = second range [hi - 2, hi): one short segment; first range [lo, hi - 2) in segments of at least
+  // two planes
+  p->second_begin = hi - 2; p->second_end = hi;
+  const int saved = p->seg_len;
+  if (p->seg_len == 1) p->seg_len = 2;
+  if (p->seg_len == 0) {
+    const int len = resolve_seg_len(p, (int)(hi - 2 - lo));
+    p->seg_len = len < 2 ? 2 : len;
+  }
+  p->signal_now = p->signal;
+  const int rc = step(p, lt::kFusedTwice, f, out, tau, lo, hi - 2, stream);
+  p->signal_now = nullptr;
+  p->seg_len = saved;
+  p->second_begin = p->second_end = 0;
+  if (rc == LT_OK) p->signal_target += 2ull * (unsigned long long)((p->n0 / tile.width) * (p->n1 / tile.rows));
+  return rc;
+}
+int lt_slab_wait_edges(lt_plan *p, void *stream) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (!p->signal) return fail(LT_ERR_INVALID, "no lt_stream_collide_twice_slab launch to wait for");
+  hipLaunchKernelGGL(lt::wait_counter_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), p->signal,
+                     p->signal_target, p->signal_timed_out);
+  LT_HIP(hipGetLastError());
+  return LT_OK;
+}
+int lt_slab_wait_timed_out(lt_plan *p, int32_t *timed_out, void *stream) {
+  if (!p || !timed_out) return fail(LT_ERR_INVALID, "null argument");
+  unsigned flag = 0;
+  if (p->signal_timed_out) {
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    LT_HIP(hipMemcpyAsync(&flag, p->signal_timed_out, sizeof flag, hipMemcpyDeviceToHost, hs));
+    LT_HIP(hipStreamSynchronize(hs));
+  }
+  *timed_out = (int32_t)flag;
+  return LT_OK;
 }
 int lt_plan_two_step_admitted(lt_plan *p) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");

@@ -30,6 +30,7 @@ struct StepArgs {
   int seg_len;           // kFusedTwice: a2 planes per workgroup; kFusedMany: steps in this launch
   void *pack_lo, *pack_hi;         // fused halo packing (slab boundary launch) or null
   int pack_lo_plane, pack_hi_plane;
+  unsigned long long *signal;      // kFusedTwice with both message buffers: edge workgroups first, each adds 1 here (or null)
   hipStream_t stream;
 };
 

@@ -74,6 +74,12 @@ struct KParams {
   // and the rows are whole waves (n0 % 64 == 0): the node next to an outlet node then sits in the next lane
   // (lbm_body); 0: none
   int abb0_slot;
+  // two-step slab launch that covers the whole slab and releases the exchange while it runs (slab layout):
+  // edge_first != 0: the workgroups of the second plane range (the upper edge) and of the first segment of
+  // the first range (the lower edge) get the lowest block indices; each of them adds 1 to *signal once its
+  // two planes next to the cut are in memory (wait_counter_kernel on the communication stream polls it)
+  unsigned long long *signal;
+  int edge_first;
 };
 
 // ---- constants the reference builds from cs = 1/np.sqrt(3.0) (lettuce/_stencil.py:17) ----
@@ -923,11 +929,28 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   // Renumber so that an XCD owns a compact patch of neighbouring tiles: the halo rows two tiles
   // share are then fetched into one L2 once instead of into two L2s.
   int b = blockIdx.x;
-  if (p.nb == 0 && gridDim.x % 8 == 0) b = (b % 8) * (gridDim.x / 8) + b / 8;
+  const int segs_a = (p.p_end - p.p_begin + seg_len - 1) / seg_len;
+  if (LAYOUT == 1 && p.edge_first) {
+    // edges first (the hardware starts workgroups in index order): upper edge = the one segment of the second
+    // range, then the first segment of the first range, then the rest with the XCD-aware numbering
+    // (XCD-aware within each layer of tiles)
+    const int tiles = tiles0 * tiles1;
+    const int layer = b / tiles, t = b - layer * tiles;
+    const int tile = tiles % 8 == 0 ? (t % 8) * (tiles / 8) + t / 8 : t;
+    b = (layer == 0 ? segs_a : layer - 1) * tiles + tile;
+  } else if (LAYOUT == 1 && p.nb == 0 && (tiles0 * tiles1) % 8 == 0) {
+    // slab launches cut their plane range into segments of unequal length (the last one is shorter): every XCD
+    // gets an eighth of EVERY segment layer -- a compact patch of tiles -- instead of an eighth of the grid
+    // (64 planes in segments of 62 + 2: four XCDs had all the long workgroups, 1.0 instead of 0.62 ms)
+    const int tiles = tiles0 * tiles1;
+    const int layer = b / tiles, t = b - layer * tiles;
+    b = layer * tiles + (t % 8) * (tiles / 8) + t / 8;
+  } else if (p.nb == 0 && gridDim.x % 8 == 0) {
+    b = (b % 8) * (gridDim.x / 8) + b / 8;
+  }
   const int t0 = (b % tiles0) * T0; b /= tiles0;
   const int t1 = (b % tiles1) * T1; b /= tiles1;
   // first output plane of this workgroup: segments of the first range, then of the second one
-  const int segs_a = (p.p_end - p.p_begin + seg_len - 1) / seg_len;
   const bool second = b >= segs_a;
   const int range_end = second ? p.p_end2 : p.p_end;
   const int s = second ? p.p_begin2 + (b - segs_a) * seg_len : p.p_begin + b * seg_len;
@@ -1039,20 +1062,33 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
         static_for<NPB>([&](auto kc) { collide_bgk<T, S, LAYOUT, NPB, decltype(kc)::value>(f, p.tau_inv); });
     }
   };
-  auto store_b = [&](int k2) {
+  // packing: this workgroup writes halo messages (PACK kernels; a launch that covers a whole slab runs the
+  // sweep of its other workgroups without that code -- with it in the loop they took twice as long)
+  // how: 0 = nontemporal stores; 1 = also the halo messages (PACK kernels); 2 = stores that are performed at
+  // device scope (write-through: another XCD's kernel may read them while this launch still runs)
+  auto store_b = [&](int k2, auto how) {
+    constexpr int HOW = decltype(how)::value;
+    constexpr bool PACKING = HOW == 1;
     if (in_b) {
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         T *base = p.out + ((long long)q * p.N + (long long)((unsigned)k2 * plane_nodes));
         static_for<NPB>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
-          __builtin_nontemporal_store(f[q][k], reinterpret_cast<T *>(reinterpret_cast<char *>(base) + out_off[k]));
+          T *at = reinterpret_cast<T *>(reinterpret_cast<char *>(base) + out_off[k]);
+          if constexpr (HOW == 2) {
+            using Bits = std::conditional_t<sizeof(T) == 4, unsigned, unsigned long long>;
+            __hip_atomic_store(reinterpret_cast<Bits *>(at), __builtin_bit_cast(Bits, f[q][k]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            __builtin_nontemporal_store(f[q][k], at);
+          }
         });
         // Slab edge launches (PACK) also write the two-step halo message (layout of halo2_kernel: in-plane
         // populations of the plane next to the cut | its crossing populations | the crossing
         // populations of the plane behind it), possibly straight into the neighbour's memory.
         constexpr int e2 = M::e(q, 2), rank = crossing_rank<S, LAYOUT, q>();
-        if constexpr (PACK) {
+        if constexpr (PACKING) {
         if (p.pack_lo != nullptr && e2 <= 0) {
           const int d = k2 - p.pack_lo_plane;                    // 0: near plane, 1: far plane
           if (d == 0 || (d == 1 && e2 < 0)) {
@@ -1086,19 +1122,60 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   load_a(s);     compute_a(1, 1);
   load_a(s + 1); compute_a(2, 2);
   if (s + 2 <= last) load_a(s + 2);
-  int r = 1, r3 = 1;                                // output plane k has relative index k - s + 1
-  for (int k = s; k < last; ++k) {
-    lds_barrier();                                  // planes up to k + 1 complete; reads of k - 1 done
-    read_b(r, r3);                                  // 19 LDS reads in flight ...
+  int r = 1, r3 = 1;                                  // output plane k has relative index k - s + 1
+  auto interval = [&](int k, auto how) {
+    lds_barrier();                                    // planes up to k + 1 complete; reads of k - 1 done
+    read_b(r, r3);                                    // 19 LDS reads in flight ...
     if (k + 2 <= last) {
-      compute_a(r + 2, r3 == 0 ? 2 : r3 - 1);       // ... behind the collide of plane k + 2; (r + 2) % 3
+      compute_a(r + 2, r3 == 0 ? 2 : r3 - 1);         // ... behind the collide of plane k + 2; (r + 2) % 3
       if (k + 3 <= last) load_a(k + 3);
     }
     collide_b();
-    store_b(k);
+    store_b(k, how);
     ++r;
     r3 = r3 == 2 ? 0 : r3 + 1;
+  };
+  int k = s;
+  using Plain = std::integral_constant<int, 0>;
+  if constexpr (PACK) {
+    // edge launches: every workgroup also writes the halo messages.  (This copy of the loop is slow -- 12 spilled
+    // registers, message stores -- and even its presence slows the other copy: a launch over the whole slab
+    // with packing first segments took 1.0 instead of 0.6 ms, so that launch does not pack.)
+    for (; k < last; ++k) interval(k, std::integral_constant<int, 1>{});
+  } else if constexpr (LAYOUT == 1) {
+    if (p.edge_first && (second || b == 0)) {
+      // Launch over the whole slab: the planes next to a cut are this workgroup's last two (upper edge) or first
+      // two (lower edge).  They are stored at device scope, and once the stores have been performed the
+      // workgroup counts itself done.  No release fence: at device scope that is a write-back of the XCD's
+      // whole L2 -- 1024 of them made the launch take 0.99 instead of 0.66 ms.
+      const int until = second ? last : (s + 2 < last ? s + 2 : last);
+      for (; k < until; ++k) interval(k, std::integral_constant<int, 2>{});
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(p.signal, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
+  for (; k < last; ++k) interval(k, Plain{});
+}
+
+// One wave on the communication stream: returns when *counter has reached `target` (the edge workgroups of
+// the launch running on the compute stream have stored the planes next to the cuts), or after about a second, setting
+// *timed_out -- an exit every launch reaches.  17 us from the last increment to the next kernel of the stream
+// (tools/experiments/stream_wait.hip; hipStreamWaitValue64 needs signal memory, where 256 device atomics
+// drained in 280 us).
+static __global__ void wait_counter_kernel(const unsigned long long *counter, unsigned long long target,
+                                           unsigned *timed_out) {
+  // relaxed polls (one uncached load each): an ACQUIRE per poll would invalidate this XCD's L2 every
+  // microsecond under the sweep that runs beside it -- measured 0.63 instead of 0.37 ms per step
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(127);
+    if (wall_clock64() - t0 > 100000000ll) {           // 100 MHz
+      *timed_out = 1u;
+      break;
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
 }
 
 // ---- up to KMAX steps per launch on small 2-D grids ---------------------------------------------

@@ -130,7 +130,15 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   // an XCD (blocks b, b + 8, ...) owns a compact patch of neighbouring tiles: shared halo rows are
   // fetched into one L2 once
   int b = blockIdx.x;
-  if (gridDim.x % 8 == 0) b = (b % 8) * (gridDim.x / 8) + b / 8;
+  if ((p.p_end - p.p_begin) % seg_len != 0 && (tiles0 * tiles1) % 8 == 0) {
+    // segments of unequal length (slab launches): an eighth of every segment layer per XCD, not an eighth of the
+    // grid -- else some XCDs get only the short last segments
+    const int tiles = tiles0 * tiles1;
+    const int layer = b / tiles, t = b - layer * tiles;
+    b = layer * tiles + (t % 8) * (tiles / 8) + t / 8;
+  } else if (gridDim.x % 8 == 0) {
+    b = (b % 8) * (gridDim.x / 8) + b / 8;
+  }
   const int t0 = (b % tiles0) * T0; b /= tiles0;
   const int t1 = (b % tiles1) * T1; b /= tiles1;
   const int s = p.p_begin + b * seg_len;           // first output plane of this workgroup

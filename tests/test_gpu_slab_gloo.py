@@ -73,31 +73,44 @@ def test_two_step_slab_ranks_sharing_one_gpu(tmp_path, world, overlap, steps, dt
 def _two_step_identity_worker(rank, port, res, steps, transport, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    if transport == "rccl":
+    if transport.startswith("rccl"):
         os.environ["LT_SLAB_FORCE_P2P"] = "1"
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     import lettuce_amd as lt
     ctx = lt.Context("cuda:0", torch.float32, use_native=True)
     outs = []
+    timed_out = False
     for driver in ("SlabSimulation", "TwoStepSlabSimulation"):
         slab = lt.ZSlab(res)
         flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 400, 0.1, lt.D3Q19(), slab=slab)
-        sim = getattr(lt, driver)(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
-                                  transport=transport)
+        kwargs = {"transport": transport.split("-")[0]}
+        if transport.endswith("-signalled"):
+            if driver == "SlabSimulation":
+                kwargs = {"transport": "rccl"}
+            else:
+                kwargs["signalled"] = True
+        sim = getattr(lt, driver)(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab, **kwargs)
         sim(steps)
         outs.append(sim.gather_f().clone())
-    np.savez(os.path.join(out_dir, "out.npz"), same=bool(torch.equal(outs[0], outs[1])))
+        if kwargs.get("signalled"):
+            assert sim._signalled_ok()
+            timed_out = sim.engine.wait_timed_out()
+    np.savez(os.path.join(out_dir, "out.npz"), same=bool(torch.equal(outs[0], outs[1])), timed_out=timed_out)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("transport", ["rccl", "window"])
+@pytest.mark.parametrize("transport", ["rccl", "window", "rccl-signalled"])
 def test_two_step_slab_is_bit_identical_to_the_single_step_slab(tmp_path, transport):
     """Same kernels' arithmetic, different schedule and halo: the two drivers must agree bit for bit
-    (single rank exchanging with itself through RCCL / through its own peer window)."""
+    (single rank exchanging with itself through RCCL / through its own peer window).  "rccl-signalled": one
+    launch per double step whose edge workgroups run first, write the messages and release the communication
+    stream through a device counter (lt_stream_collide_twice_slab + lt_slab_wait_messages); its polling wave
+    must never have given up."""
     mp.spawn(_two_step_identity_worker, args=(29950 + os.getpid() % 1000, [64, 32, 16], 9, transport, str(tmp_path)),
              nprocs=1, join=True)
-    assert bool(np.load(tmp_path / "out.npz")["same"])
+    got = np.load(tmp_path / "out.npz")
+    assert bool(got["same"]) and not bool(got["timed_out"])
 
 
 def _golden_slab_worker(rank, port, res, steps, out_dir):
