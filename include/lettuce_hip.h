@@ -292,7 +292,8 @@ const char *lt_plan_kernel_name(lt_plan *plan);
 /* A/B selector.  16-byte variant of the one-step kernel: 0 = aligned vector load + one neighbour
  * element, 1 = unaligned vector load, 2 = aligned vector load + cross-lane shift.  Two-step kernel
  * (D3Q19 / D3Q15 fp32, BGK, reference layout): 0 = product variant, 1 = two nodes per thread in both
- * phases, 2 = two output nodes per thread, 3 = no XCD-aware renumbering of the workgroups. */
+ * phases, 2 = two output nodes per thread, 3 = no XCD-aware renumbering of the workgroups, 4 = the round-1
+ * renumbering (an eighth of the grid per XCD instead of an eighth of every segment layer). */
 int lt_plan_set_shift_policy(lt_plan *plan, int32_t policy);
 /* Diagnostic: dst[0:n_bytes] = src[0:n_bytes] with 16-byte accesses and the cache-policy bits of
  * lt_plan_set_tuning; max_blocks > 0 caps its grid (grid-stride loop).  bench.py uses it to

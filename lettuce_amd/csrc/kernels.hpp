@@ -938,15 +938,16 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
     const int layer = b / tiles, t = b - layer * tiles;
     const int tile = tiles % 8 == 0 ? (t % 8) * (tiles / 8) + t / 8 : t;
     b = (layer == 0 ? segs_a : layer - 1) * tiles + tile;
-  } else if (LAYOUT == 1 && p.nb == 0 && (tiles0 * tiles1) % 8 == 0) {
-    // slab launches cut their plane range into segments of unequal length (the last one is shorter): every XCD
-    // gets an eighth of EVERY segment layer -- a compact patch of tiles -- instead of an eighth of the grid
-    // (64 planes in segments of 62 + 2: four XCDs had all the long workgroups, 1.0 instead of 0.62 ms)
+  } else if (p.nb == 0 && (tiles0 * tiles1) % 8 == 0) {
+    // every XCD gets an eighth of EVERY segment layer -- a compact patch of tiles -- rather than an eighth of
+    // the grid: slab launches cut their plane range into segments of unequal length (64 planes as 62 + 2: four
+    // XCDs had all the long workgroups, 1.00 instead of 0.55 ms), and with equal segments it is as good or
+    // better (256^3: 0.511 / 0.537 / 0.532 against 0.512 / 0.572 / 0.579 ms with 128 / 64 / 32 planes)
     const int tiles = tiles0 * tiles1;
     const int layer = b / tiles, t = b - layer * tiles;
     b = layer * tiles + (t % 8) * (tiles / 8) + t / 8;
-  } else if (p.nb == 0 && gridDim.x % 8 == 0) {
-    b = (b % 8) * (gridDim.x / 8) + b / 8;
+  } else if (p.nb != 1 && gridDim.x % 8 == 0) {
+    b = (b % 8) * (gridDim.x / 8) + b / 8;           // A/B (nb = 2), or tiles that do not divide by 8
   }
   const int t0 = (b % tiles0) * T0; b /= tiles0;
   const int t1 = (b % tiles1) * T1; b /= tiles1;

@@ -130,9 +130,9 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   // an XCD (blocks b, b + 8, ...) owns a compact patch of neighbouring tiles: shared halo rows are
   // fetched into one L2 once
   int b = blockIdx.x;
-  if ((p.p_end - p.p_begin) % seg_len != 0 && (tiles0 * tiles1) % 8 == 0) {
-    // segments of unequal length (slab launches): an eighth of every segment layer per XCD, not an eighth of the
-    // grid -- else some XCDs get only the short last segments
+  if ((tiles0 * tiles1) % 8 == 0) {
+    // an eighth of every segment layer per XCD, not an eighth of the grid: with segments of unequal length
+    // (slab launches) some XCDs would get only the short last segments (see lbm2_kernel)
     const int tiles = tiles0 * tiles1;
     const int layer = b / tiles, t = b - layer * tiles;
     b = layer * tiles + (t % 8) * (tiles / 8) + t / 8;
