@@ -323,9 +323,12 @@ int lt_stream_collide_twice(lt_plan *plan, const void *f_dev, void *out_dev, dou
 /* Small 2-D grids (launch-bound): n_steps <= 8 stream-collide steps in one launch.  Every workgroup
  * keeps the neighbourhood of its 8 x 8 tile in LDS and recomputes the halo, so the launch does
  * redundant arithmetic but replaces n_steps launches; bit-identical to n_steps lt_stream_collide
- * calls.  2-D lattices, no masks, extents multiples of 8; LT_ERR_UNSUPPORTED otherwise.
+ * calls.  2-D lattices, extents multiples of 8; plans with masks too (bounce-back, equilibrium and at most
+ * one anti-bounce-back outlet, for which one more ring of nodes is recomputed: n_steps <= 7);
+ * LT_ERR_UNSUPPORTED otherwise.
  * lt_plan_set_many_step: lt_run / lt_continue use it for their fused steps: -1 = automatic (grids up
- * to 256 x 256 nodes, BGK / no collision, where it is bit-identical to the one-step kernel),
+ * to 256 x 256 nodes, with masks up to 128 x 64; BGK / no collision, where it is bit-identical to the
+ * one-step kernel),
  * 0 = never, 1 = whenever supported. */
 int lt_stream_collide_many(lt_plan *plan, const void *f_dev, void *out_dev, double tau, int32_t n_steps,
                            void *stream);

@@ -378,8 +378,8 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   if (p->desc.ghost_planes && (pb < 1 || pe > p->n2 - 1) && mode != lt::kCollideOnly && pe > pb)
     return fail(LT_ERR_INVALID, "streaming from ghost planes: range [%lld, %lld) must stay in [1, %d)",
                 pb, pe, p->n2 - 1);
-  if (mode == lt::kFusedMany && (p->masked || p->desc.ghost_planes))
-    return fail(LT_ERR_UNSUPPORTED, "several steps per launch: no masks / boundaries / slabs");
+  if (mode == lt::kFusedMany && (p->desc.ghost_planes || (p->masked && p->n_abb > 1)))
+    return fail(LT_ERR_UNSUPPORTED, "several steps per launch: no slabs, at most one anti-bounce-back outlet");
   if (mode == lt::kFusedTwice) {
     if (p->desc.ghost_planes == 1)
       return fail(LT_ERR_INVALID, "two steps per launch read two planes beyond the range: the plan needs "
@@ -410,6 +410,7 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.masked = p->masked;
   a.abb_depth = p->n_abb > 1 ? p->n_abb - 1 : 0;
   a.abb_axis = p->masked ? masked_two_step_axis(p) : 2;
+  a.n_abb = p->masked ? p->n_abb : 0;
   a.abb0_slot = 0;
   if (p->masked && p->n_abb == 1)
     for (int i = 0; i < p->desc.n_boundaries; ++i) {
@@ -541,22 +542,29 @@ bool two_step_wanted(lt_plan *p) {
 }
 
 constexpr int kManyMax = 8;        // == kManyMax of unit.inc
+// steps per many-step launch: a plan with an outlet recomputes one more ring of nodes around each tile
+int many_max(const lt_plan *p) { return kManyMax - ((p->masked && p->n_abb > 0) ? 1 : 0); }
 
 // Several steps per launch (lbm_many_kernel): 2-D, no masks, tiles of 8 x 8.  Every workgroup
 // recomputes a halo of K - 1 nodes around its tile, so this only pays while the grid is
 // launch-bound; "automatic" stops at 256 x 256 nodes (measured, tools/small_grid_bench.py).
 bool many_step_wanted(lt_plan *p) {
-  if (p->many == 0 || p->masked || p->desc.ghost_planes || p->unit.d != 2) return false;
+  if (p->many == 0 || p->desc.ghost_planes || p->unit.d != 2) return false;
+  if (p->masked && p->n_abb > 1) return false;
   if (p->n0 % 8 != 0 || p->n1 % 8 != 0) return false;
   lt::StepArgs a;
   memset(&a, 0, sizeof a);
   a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = lt::kFusedMany;
+  a.masked = p->masked;
   if (!p->unit.name(a)) return false;
   if (p->many == 1) return true;
   // automatic only where the many-step kernel is bit-identical to the one-step kernel, so that the
   // result of n steps does not depend on how the caller splits them into batches (KBC agrees at
   // rounding level only)
   if (p->desc.collision == LT_COLLISION_KBC) return false;
+  // with masks the launch is bound by its own latency chain (node bytes, boundary table, seven barriers) and
+  // recomputes a wider ring: 128 x 64 nodes 4.1 -> 2.7 us per step, 256 x 128 4.5 -> 4.9 (tools/small_masked_bench.py)
+  if (p->masked) return p->N <= 128ll * 64ll;
   return p->N <= 256ll * 256ll;
 }
 
@@ -590,7 +598,7 @@ int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, 
     // launches of up to kManyMax steps each; the events bracket them
     if (p->ev_start) (void)hipEventRecord(p->ev_start, hs);
     while (fused > 0) {
-      p->many_now = fused < kManyMax ? (int)fused : kManyMax;
+      p->many_now = fused < many_max(p) ? (int)fused : many_max(p);
       rc = step(p, lt::kFusedMany, cur, other, tau, 0, p->n2, stream);
       if (rc) return rc;
       void *t = cur; cur = other; other = t;
@@ -1097,7 +1105,8 @@ int lt_plan_last_run_info(lt_plan *p, int64_t *single_step_launches, int64_t *tw
 
 int lt_stream_collide_many(lt_plan *p, const void *f, void *out, double tau, int32_t n_steps, void *stream) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
-  if (n_steps < 1 || n_steps > kManyMax) return fail(LT_ERR_INVALID, "n_steps = %d (1..%d per launch)", n_steps, kManyMax);
+  if (n_steps < 1 || n_steps > many_max(p))
+    return fail(LT_ERR_INVALID, "n_steps = %d (1..%d per launch for this plan)", n_steps, many_max(p));
   p->many_now = n_steps;
   return step(p, lt::kFusedMany, f, out, tau, 0, p->n2, stream);
 }

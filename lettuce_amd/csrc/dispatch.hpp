@@ -24,6 +24,7 @@ struct StepArgs {
   int layout, coll, mode, masked, wide, shift, tune;
   int strip;             // kFusedTwice on 2-D lattices: columns per workgroup (512 / 256 / 128 / 64)
   int abb_axis;          // kFusedTwice with masks: memory axis of the plan's outlet (2 without one)
+  int n_abb;             // anti-bounce-back outlets of the plan
   int abb0_slot;         // one-step kernels: 1-based index of the plan's only outlet if its normal is memory axis a0, else 0
   int abb_depth;         // anti-bounce-back outlets of the plan - 1 (0: at most one; the kernels exist for 0 and 1)
   int lds_bytes;         // unused dynamic LDS per workgroup (residency cap), 0 = none

@@ -1194,7 +1194,15 @@ struct ManyStep2D {
   static constexpr int THREADS = (NR + 63) / 64 * 64;
 };
 
-template <typename T, class S, int COLL, int TO0, int TO1, int KMAX>
+// MASKED: plans with boundaries.  A thread keeps its node for all K steps, so the node byte, the no-streaming
+// bits and -- on an equilibrium node -- the populations the boundary writes are fetched once.  A slot with a
+// no-streaming bit keeps the node's own value of the step before (global memory in step 1, the LDS buffer
+// afterwards).  The anti-bounce-back outlet needs (rho, j) of the node next to it as the one-step kernel sees
+// them: the moments of that node's pulled populations, which are rebuilt from the same source as the thread's
+// own pull (neighbour_moments in step 1, the LDS buffer afterwards).  That neighbour must itself be valid, so
+// plans with an outlet recompute one more ring (halo = K instead of K - 1: at most KMAX - 1 steps per launch).
+// Same functions in the same order as lbm_body: K launches of the masked lbm_kernel give the same bits.
+template <typename T, class S, int COLL, int TO0, int TO1, int KMAX, bool MASKED = false>
 __global__ void __launch_bounds__((ManyStep2D<TO0, TO1, KMAX>::THREADS))
 lbm_many_kernel(const KParams<T> p, const int K) {
   static_assert(S::D == 2, "2-D lattices");
@@ -1202,7 +1210,7 @@ lbm_many_kernel(const KParams<T> p, const int K) {
   using G = ManyStep2D<TO0, TO1, KMAX>;
   __shared__ T lds[2][S::Q][G::NR];
   const int tid = threadIdx.x;
-  const int halo = K - 1;
+  const int halo = K - 1 + (MASKED ? p.abb0_slot : 0);        // abb0_slot: 1 = the plan has an outlet
   const int r0 = TO0 + 2 * halo, r1 = TO1 + 2 * halo;        // neighbourhood of this launch
   const int tiles0 = p.n0 / TO0;
   const int t0 = (blockIdx.x % tiles0) * TO0, t1 = (blockIdx.x / tiles0) * TO1;
@@ -1210,9 +1218,71 @@ lbm_many_kernel(const KParams<T> p, const int K) {
   const int i1 = tid / r0, i0 = tid - i1 * r0;
   auto wrap = [](int x, int n) { x %= n; return x < 0 ? x + n : x; };
   const int g0 = wrap(t0 - halo + i0, p.n0), g1 = wrap(t1 - halo + i1, p.n1);
+  const unsigned own = (unsigned)g1 * (unsigned)p.n0 + (unsigned)g0;
   auto collide = [&](T (&f)[S::Q][1]) {
     if constexpr (COLL == 1) collide_bgk<T, S, 0, 1, 0>(f, p.tau_inv);
     if constexpr (COLL == 2) collide_kbc<T, S, 0, 1, 0>(f, p.beta, p.inv_beta);
+  };
+  // ---- boundaries (MASKED) ----
+  int bidx = 0;
+  unsigned bits = 0;
+  T eqv[S::Q];                                          // what this node's equilibrium boundary writes
+  if constexpr (MASKED) {
+    if (in_region) {
+      const unsigned char nd = p.node[own];
+      bidx = nd & 0x7f;
+      if (nd & 0x80) bits = p.nsm_bits[own];
+      if (bidx != 0 && p.bt->kind[bidx] == kEquilibrium) {
+        const T *fld = p.bt->field[bidx];
+        static_for<S::Q>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          eqv[q] = fld ? fld[(long long)q * p.N + own] : p.bt->feq[bidx][q];
+        });
+      }
+    }
+  }
+  // an outlet node: index, node byte and no-streaming bits of the node next to it (fetched once)
+  unsigned nown = 0, nbits = 0;
+  int nbidx = 0;
+  if constexpr (MASKED) {
+    if (in_region && p.abb0_slot) {
+      for (int slot = 1; slot <= p.nb; ++slot)
+        if (p.bt->kind[slot] == kAbbOutlet) {
+          const int ax = p.bt->mem_axis[slot];
+          if ((ax == 0 ? g0 : g1) == p.bt->plane[slot]) {
+            const int ng0 = ax == 0 ? p.bt->nbr[slot] : g0, ng1 = ax == 1 ? p.bt->nbr[slot] : g1;
+            nown = (unsigned)ng1 * (unsigned)p.n0 + (unsigned)ng0;
+            const unsigned char nnd = p.node[nown];
+            nbidx = nnd & 0x7f;
+            nbits = (nnd & 0x80) ? p.nsm_bits[nown] : 0u;
+          }
+        }
+    }
+  }
+  // collision and the boundaries in index order; nbr(slot, rho, j): moments of the node next to an outlet node
+  auto collide_and_bound = [&](T (&f)[S::Q][1], auto &&nbr) {
+    if constexpr (!MASKED) {
+      collide(f);
+    } else {
+      if (bidx == 0) collide(f);
+      for (int slot = 1; slot <= p.nb; ++slot) {
+        const int kind = p.bt->kind[slot];
+        if (kind == kAbbOutlet) {
+          const int ax = p.bt->mem_axis[slot];
+          if ((ax == 0 ? g0 : g1) == p.bt->plane[slot]) {
+            T rn, jn[3];
+            nbr(slot, rn, jn);
+            abb_apply<T, S, 0, 1, 0>(p, slot, rn, jn, f);
+          }
+        } else if (bidx == slot) {
+          if (kind == kBounceBack) {
+            bounce_back<T, S, 1, 0>(f);
+          } else if (kind == kEquilibrium) {
+            static_for<S::Q>([&](auto qc) { f[decltype(qc)::value][0] = eqv[decltype(qc)::value]; });
+          }
+        }
+      }
+    }
   };
   T f[S::Q][1];
   // step 1: pull from global memory, every node of the neighbourhood
@@ -1222,8 +1292,14 @@ lbm_many_kernel(const KParams<T> p, const int K) {
       constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1);
       const int s0 = e0 == 0 ? g0 : wrap(g0 - e0, p.n0), s1 = e1 == 0 ? g1 : wrap(g1 - e1, p.n1);
       f[q][0] = p.in[(long long)q * p.N + (long long)s1 * p.n0 + s0];
+      if constexpr (MASKED && q > 0) {
+        if (bits & (1u << q)) f[q][0] = p.in[(long long)q * p.N + own];
+      }
     });
-    collide(f);
+    collide_and_bound(f, [&](int slot, T &rn, T (&jn)[3]) {
+      const int ax = p.bt->mem_axis[slot], nb = p.bt->nbr[slot];
+      neighbour_moments<T, S, 0, true, true, COLL, 0>(p, ax == 0 ? nb : g0, ax == 1 ? nb : g1, 0, slot, rn, jn);
+    });
   }
   for (int s = 1; s < K; ++s) {                 // f holds the state after step s
     const int buf = s & 1;
@@ -1241,13 +1317,30 @@ lbm_many_kernel(const KParams<T> p, const int K) {
         constexpr int q = decltype(qc)::value;
         constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1);
         f[q][0] = lds[buf][q][(i1 - e1) * G::R0 + (i0 - e0)];
+        if constexpr (MASKED && q > 0) {
+          if (bits & (1u << q)) f[q][0] = lds[buf][q][i1 * G::R0 + i0];
+        }
       });
-      collide(f);
+      collide_and_bound(f, [&](int slot, T &rn, T (&jn)[3]) {
+        // the node next to this outlet node, inside the domain: its pull from the same LDS state
+        const int ax = p.bt->mem_axis[slot], side = p.bt->side[slot];
+        const int n0i = ax == 0 ? i0 - side : i0, n1i = ax == 1 ? i1 - side : i1;
+        T g[S::Q][1];
+        static_for<S::Q>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1);
+          g[q][0] = lds[buf][q][(n1i - e1) * G::R0 + (n0i - e0)];
+          if constexpr (q > 0) {
+            if (nbits & (1u << q)) g[q][0] = lds[buf][q][n1i * G::R0 + n0i];
+          }
+        });
+        moments<T, S, 0, 1, 0>(g, rn, jn);
+        lower_boundaries_on_moments<T, S, 0>(p, nbidx, slot, nown, rn, jn);
+      });
     }
   }
   // after K steps the valid nodes are the tile
   if (in_region && i0 >= halo && i0 < r0 - halo && i1 >= halo && i1 < r1 - halo) {
-    const long long own = (long long)g1 * p.n0 + g0;
     static_for<S::Q>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       p.out[(long long)q * p.N + own] = f[q][0];

@@ -408,6 +408,11 @@ if __name__ == "__main__":
     tgv_case("tgv3d_d3q19_bgk_32_f32", 32, lt.D3Q19(), 1600, 0.1, "f32", "bgk", {10}, 10)
     obstacle_case("obstacle2d_d2q9_bgk_f64", [32, 20], lt.D2Q9(), "f64", "bgk", {1, 2, 10},
                   4.0, (1.0, 1.25), 0.4)
+    # extents that are multiples of 8: the many-steps-per-launch kernel with masks
+    obstacle_case("obstacle2d_d2q9_bgk_40x24_f64", [40, 24], lt.D2Q9(), "f64", "bgk", {1, 2, 9, 20},
+                  4.0, (1.0, 1.2), 0.4)
+    obstacle_case("obstacle2d_d2q9_bgk_40x24_f32", [40, 24], lt.D2Q9(), "f32", "bgk", {1, 2, 9, 20},
+                  4.0, (1.0, 1.2), 0.4)
     obstacle_case("obstacle3d_d3q27_kbc_f64", [20, 12, 12], lt.D3Q27(), "f64", "kbc", {1, 2, 8},
                   4.0, (1.0, 1.2, 1.2), 0.5)
     obstacle_case("obstacle3d_d3q27_kbc_f32", [20, 12, 12], lt.D3Q27(), "f32", "kbc", {2, 8},

@@ -881,6 +881,61 @@ def test_many_steps_per_launch_equal_single_steps(res, coll, dt):
             assert torch.equal(got, a), k
 
 
+MANY_MASKED = [([16, 24], None), ([24, 16], (0, 1)), ([24, 16], (0, -1)), ([16, 32], (1, 1)), ([8, 40], (1, -1)), ([8, 8], (0, 1))]
+
+
+@pytest.mark.parametrize("res,abb", MANY_MASKED, ids=[f"{'x'.join(map(str, r))}-{a}" for r, a in MANY_MASKED])
+@pytest.mark.parametrize("coll,dt", [("bgk", "f64"), ("bgk", "f32"), ("none", "f32")])
+@pytest.mark.parametrize("variant", ["table", "field-outlet-first"])
+def test_many_steps_per_launch_with_boundaries_equal_single_steps(res, abb, coll, dt, variant):
+    """lbm_many_kernel<..., MASKED>: random bounce-back / equilibrium nodes (table or per-node field), no-streaming
+    bits and an anti-bounce-back outlet along either axis, before or after the other boundaries in index order: K
+    steps in one launch == K masked one-step launches, bit for bit, for every K (7 with an outlet: one more
+    ring of nodes is recomputed so that the outlet's neighbour is valid)."""
+    dtype = TORCH_DT[dt]
+    f0, ncm, nsm, entries = _masked_case("D2Q9", res, dtype, abb, 41, with_field=(variant != "table"),
+                                         abb_first=(variant != "table"))
+    if abb is None:
+        nsm[3, 2, 5] = 1                                   # stray no-streaming bits on ordinary nodes
+        nsm[7, 6, 1] = 1
+    plan = plan_for("D2Q9", dtype, coll, res, entries)
+    plan.set_masks(dev(ncm), dev(nsm))
+    f = dev(f0)
+    a, b = f.clone(), torch.empty_like(f)
+    kmax = 8 if abb is None else 7
+    for k in range(1, kmax + 1):
+        plan.stream_collide(a, b, 0.7)
+        a, b = b, a
+        got = torch.full_like(f, float("nan"))
+        plan.stream_collide_many(f, got, 0.7, k)
+        np.testing.assert_array_equal(got.cpu().numpy(), a.cpu().numpy(), err_msg=f"K = {k}")
+    if abb is not None:
+        with pytest.raises(Exception, match="n_steps"):
+            plan.stream_collide_many(f, got, 0.7, 8)
+
+
+MANY_GOLDEN = [("obstacle2d_d2q9_bgk_40x24_f64", "f64"), ("obstacle2d_d2q9_bgk_40x24_f32", "f32")]
+
+
+@pytest.mark.parametrize("name,dt", MANY_GOLDEN, ids=[t[0] for t in MANY_GOLDEN])
+def test_many_step_launches_on_the_obstacle_vectors_of_the_reference(name, dt):
+    """The reference's 2-D Obstacle (inlet, outlet, cylinder) on a grid of multiples of 8: lt_run packs its fused
+    steps into launches of up to 7, the result equals the step-by-step path exactly and the reference's
+    populations at the outlet's rounding level."""
+    g = golden(name)
+    plan = obstacle_plan(g, "D2Q9", "bgk", dt)
+    for n in (1, 2, 9, 20):
+        plan.set_many_step(0)
+        single = run_engine(plan, g["f0"], float(g["tau"]), n)
+        plan.set_many_step(-1)                              # automatic: 40 x 24 nodes are well below the limit
+        packed = run_engine(plan, g["f0"], float(g["tau"]), n)
+        info = plan.last_run_info()
+        assert info["many_step_launches"] == (0 if n < 3 else -(-(n - 1) // 7)), info
+        np.testing.assert_array_equal(packed, single)
+        assert_close(packed, g[f"f{n}"], dt, scale=10 if dt == "f64" else 1)
+    assert "lbm_many_kernel" in plan.kernel_name() and "true" in plan.kernel_name()
+
+
 def test_lt_run_uses_many_step_launches_on_small_2d_grids():
     """cfg1's shape: lt_run issues ceil((n-1)/8) launches for its fused steps and the populations are
     those of the step-by-step path (and bit-identical to the reference vectors, tested elsewhere)."""
