@@ -25,7 +25,7 @@ def main():
     eng, lo, hi = sim.engine, sim.lo, sim.hi
     a, b = sim.f, sim.f_next
     out = {}
-    for seg in (0, 16, 32, res[2] // 2 - 1 if res[2] > 64 else 62):
+    for seg in ([int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else (0, 16, 32, res[2] // 2 - 1 if res[2] > 64 else 62)):
         eng.set_two_step(1, seg)
         out[f"planes seg{seg}"] = timed(lambda: eng.stream_collide_twice_planes(a, b, 0.53, lo, hi))
         out[f"slab launch seg{seg}"] = timed(lambda: eng.stream_collide_twice_slab(a, b, 0.53))
