@@ -1026,6 +1026,8 @@ int lt_stream_collide_twice_slab(lt_plan *p, const void *f, void *out, double ta
     LT_HIP(hipMalloc((void **)&p->signal_timed_out, sizeof(unsigned)));
     LT_HIP(hipMemsetAsync(p->signal, 0, sizeof(unsigned long long), hs));
     LT_HIP(hipMemsetAsync(p->signal_timed_out, 0, sizeof(unsigned), hs));
+    // once: the polling wave of ANOTHER stream must never see the counter before it is zero
+    LT_HIP(hipStreamSynchronize(hs));
     p->signal_target = 0;
   }
   const TwoStepTile tile = two_step_tile(p);

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, res, steps, dtype_name, overlap, out_dir, driver="SlabSimulation"):
+def _worker(rank, world, port, res, steps, dtype_name, overlap, out_dir, driver="SlabSimulation", signalled=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -25,9 +25,12 @@ def _worker(rank, world, port, res, steps, dtype_name, overlap, out_dir, driver=
     ctx = lt.Context("cuda:0", getattr(torch, dtype_name), use_native=True)
     slab = lt.ZSlab(res)
     flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 400, 0.1, lt.D3Q19(), slab=slab)
+    kwargs = {"signalled": True} if signalled else {}
     sim = getattr(lt, driver)(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
-                              overlap=overlap)
+                              overlap=overlap, **kwargs)
     sim(steps)
+    if signalled:
+        assert sim._signalled_ok() and not sim.engine.wait_timed_out()
     f1 = sim.gather_f()
     ke = sim.kinetic_energy_pu()
     if rank == 0:
@@ -51,17 +54,20 @@ def test_ranks_sharing_one_gpu(tmp_path, world, overlap):
     assert float(got["ke"]) == pytest.approx(float(orc.kinetic_energy_pu(ref.f, ref.lat, ref.units)), rel=1e-11)
 
 
-@pytest.mark.parametrize("world,overlap,steps,dtype_name", [(2, True, 7, "float32"), (2, False, 6, "float32"),
-                                                            (3, True, 4, "float32"), (2, True, 5, "float64")],
-                         ids=["2ranks-overlap-7steps", "2ranks-serial-6steps", "3ranks-overlap-4steps", "2ranks-fp64"])
-def test_two_step_slab_ranks_sharing_one_gpu(tmp_path, world, overlap, steps, dtype_name):
+@pytest.mark.parametrize("world,overlap,steps,dtype_name,signalled",
+                         [(2, True, 7, "float32", False), (2, False, 6, "float32", False), (3, True, 4, "float32", False),
+                          (2, True, 5, "float64", False), (2, True, 8, "float32", True), (3, True, 5, "float64", True)],
+                         ids=["2ranks-overlap-7steps", "2ranks-serial-6steps", "3ranks-overlap-4steps", "2ranks-fp64",
+                              "2ranks-signalled", "3ranks-signalled-fp64"])
+def test_two_step_slab_ranks_sharing_one_gpu(tmp_path, world, overlap, steps, dtype_name, signalled):
     """TwoStepSlabSimulation with the real kernels (lt_stream_collide_twice_planes on slabs with two
     ghost planes, lt_slab_pack/unpack_two_step) on 2-3 gloo ranks sharing the GPU, fp32, against the
     single-domain oracle; boundary / interior launches on two streams when overlapping."""
     from oracle import lettuce_oracle as orc
     res = [64, 16, 12 * world]
     port = 29600 + (os.getpid() % 1000) + int(overlap) + 10 * world
-    mp.spawn(_worker, args=(world, port, res, steps, dtype_name, overlap, str(tmp_path), "TwoStepSlabSimulation"),
+    port += 100 if signalled else 0
+    mp.spawn(_worker, args=(world, port, res, steps, dtype_name, overlap, str(tmp_path), "TwoStepSlabSimulation", signalled),
              nprocs=world, join=True)
     got = np.load(tmp_path / "out.npz")
     ref = orc.taylor_green(res, 400, 0.1, "D3Q19", getattr(torch, dtype_name))
