@@ -316,9 +316,11 @@ int lt_plan_set_tuning(lt_plan *plan, int32_t cache_policy, int32_t wide);
  * Bit-identical to two lt_stream_collide calls.  Exists with BGK / no collision for the 3-D lattices
  * (D3Q15 and D3Q19 in fp32 and fp64, D3Q27 in fp32) on grids whose contiguous extent is a multiple
  * of 64 (fp32) / 32 (fp64) and whose middle extent is a multiple of 8 (D3Q27: of 4), for D2Q9 (fp32 and
- * fp64) on grids whose contiguous extent is a multiple of 64, and -- 3-D, fp32 and D3Q15 fp64 -- for plans
- * with bounce-back / equilibrium boundaries and an anti-bounce-back outlet at the last plane of the
- * slowest memory axis (no-streaming bits exactly that outlet's); LT_ERR_UNSUPPORTED otherwise. */
+ * fp64) on grids whose contiguous extent is a multiple of 64, and -- D2Q9; 3-D in fp32 and D3Q15 fp64 -- for
+ * plans with bounce-back / equilibrium boundaries and at most one anti-bounce-back outlet: at the last plane
+ * (2-D: row) of the slowest memory axis or, in 3-D, at an end of the contiguous axis opposite a face of
+ * equilibrium nodes (no-streaming bits exactly that outlet's); LT_ERR_UNSUPPORTED otherwise
+ * (lt_plan_two_step_admitted tells). */
 int lt_stream_collide_twice(lt_plan *plan, const void *f_dev, void *out_dev, double tau, void *stream);
 /* Small 2-D grids (launch-bound): n_steps <= 8 stream-collide steps in one launch.  Every workgroup
  * keeps the neighbourhood of its 8 x 8 tile in LDS and recomputes the halo, so the launch does

@@ -354,15 +354,23 @@ int halo2(lt_plan *p, bool do_pack, void *f, int side, void *buf, void *stream) 
 // Returns the memory axis of the outlet (2 without one), or -1: not admitted.
 int masked_two_step_axis(const lt_plan *p) {
   if (!p->nsm_confined) return -1;
+  const int sweep = p->unit.d == 2 ? 1 : 2;          // the slowest memory axis
+  if (p->unit.d < 2) return -1;
   int n_abb = 0, axis = 2;
   for (int i = 0; i < p->desc.n_boundaries; ++i) {
     const lt_boundary_desc &b = p->desc.boundaries[i];
     if (b.kind != LT_BOUNDARY_ABB_OUTLET || (b.flags & LT_BOUNDARY_ABSENT)) continue;
     if (++n_abb > 1) return -1;
-    axis = mem_axis_of(p, b.axis);
-    if (axis == 2 && (b.side != 1 || p->n2 < 3)) return -1;
-    if (axis == 0 && !p->inlet_faces_outlet) return -1;
-    if (axis == 1) return -1;
+    const int ax = mem_axis_of(p, b.axis);
+    if (ax == sweep) {
+      if (b.side != 1 || (sweep == 2 ? p->n2 : p->n1) < 3) return -1;
+      axis = 2;                                      // "at the last plane / row of the sweep"
+    } else if (ax == 0 && p->unit.d == 3) {
+      if (!p->inlet_faces_outlet) return -1;
+      axis = 0;
+    } else {
+      return -1;
+    }
   }
   return axis;
 }
@@ -765,15 +773,16 @@ int lt_plan_set_masks(lt_plan *p, const uint8_t *ncm, const uint8_t *nsm, void *
   // slowest memory axis or at an end of the rows -- the populations entering through it, on every node of it
   int axis = -1, plane = -1, face = -1, outlets = 0;
   unsigned expected = 0, eq_slots = 0;
+  const int sweep = p->unit.d == 2 ? 1 : 2;          // the slowest memory axis: rows in 2-D, planes in 3-D
   for (int i = 0; i < p->desc.n_boundaries; ++i) {
     const lt_boundary_desc &b = p->desc.boundaries[i];
     if (b.kind == LT_BOUNDARY_EQUILIBRIUM) eq_slots |= 1u << (i + 1);
     if (b.kind != LT_BOUNDARY_ABB_OUTLET || (b.flags & LT_BOUNDARY_ABSENT)) continue;
     ++outlets;
     const int ax = mem_axis_of(p, b.axis);
-    if ((ax == 2 && b.side == 1) || ax == 0) {
-      axis = ax;
-      plane = ax == 2 ? p->n2 - 1 - p->desc.ghost_planes : (b.side == 1 ? p->n0 - 1 : 0);
+    if ((ax == sweep && b.side == 1) || (ax == 0 && p->unit.d == 3)) {
+      axis = ax == sweep ? 2 : 0;                    // compile_masks_kernel: 2 = "index / plane_nodes", 0 = a0 column
+      plane = ax == sweep ? (sweep == 2 ? p->n2 : p->n1) - 1 - p->desc.ghost_planes : (b.side == 1 ? p->n0 - 1 : 0);
       if (ax == 0) face = b.side == 1 ? 0 : p->n0 - 1;
       const lt::QList in = crossing_axis(p, ax, -b.side);
       for (int k = 0; k < in.n; ++k) expected |= 1u << in.q[k];
@@ -782,7 +791,8 @@ int lt_plan_set_masks(lt_plan *p, const uint8_t *ncm, const uint8_t *nsm, void *
   if (outlets != 1) { axis = -1; plane = -1; face = -1; expected = 0; }
   const unsigned grid = (unsigned)((p->N + lt::kThreads - 1) / lt::kThreads);
   hipLaunchKernelGGL(lt::compile_masks_kernel, dim3(grid), dim3(lt::kThreads), 0, hs, ncm, nsm, p->unit.q, p->N,
-                     p->node, nsm ? p->nsm_bits : nullptr, (long long)p->n0 * p->n1, p->n0, axis, plane, expected,
+                     p->node, nsm ? p->nsm_bits : nullptr, sweep == 1 ? (long long)p->n0 : (long long)p->n0 * p->n1, p->n0,
+                     axis, plane, expected,
                      face, eq_slots, p->mask_flag);
   LT_HIP(hipGetLastError());
   unsigned flags = 0;

@@ -411,6 +411,9 @@ if __name__ == "__main__":
     # extents that are multiples of 8: the many-steps-per-launch kernel with masks
     obstacle_case("obstacle2d_d2q9_bgk_40x24_f64", [40, 24], lt.D2Q9(), "f64", "bgk", {1, 2, 9, 20},
                   4.0, (1.0, 1.2), 0.4)
+    # contiguous extent % 64: the two-step kernel with masks in two dimensions
+    obstacle_case("obstacle2d_d2q9_bgk_24x64_f64", [24, 64], lt.D2Q9(), "f64", "bgk", {1, 2, 3, 8},
+                  4.0, (1.0, 5.0), 0.7)
     obstacle_case("obstacle2d_d2q9_bgk_40x24_f32", [40, 24], lt.D2Q9(), "f32", "bgk", {1, 2, 9, 20},
                   4.0, (1.0, 1.2), 0.4)
     obstacle_case("obstacle3d_d3q27_kbc_f64", [20, 12, 12], lt.D3Q27(), "f64", "kbc", {1, 2, 8},

@@ -87,6 +87,7 @@ def test_cfg1_anchor_energies():
 
 OBST = [("obstacle2d_d2q9_bgk_f64", "D2Q9", "bgk", "f64", (1, 2, 10)),
         ("obstacle2d_d2q9_bgk_40x24_f64", "D2Q9", "bgk", "f64", (1, 2, 9, 20)),
+        ("obstacle2d_d2q9_bgk_24x64_f64", "D2Q9", "bgk", "f64", (1, 2, 3, 8)),
         ("obstacle2d_d2q9_bgk_40x24_f32", "D2Q9", "bgk", "f32", (1, 2, 9, 20)),
         ("obstacle3d_d3q27_kbc_f64", "D3Q27", "kbc", "f64", (1, 2, 8)),
         ("obstacle3d_d3q27_kbc_f32", "D3Q27", "kbc", "f32", (2, 8)),
