@@ -540,6 +540,10 @@ class TwoStepSlabSimulation(SlabSimulation):
         if int(refused.item()):
             raise LettuceException("the two-step slab driver cannot run this flow"
                                    + (f": {why}" if why else " (refused on another rank)"))
+        if self._masked and flow.stencil.q == 27:
+            import warnings
+            warnings.warn("TwoStepSlabSimulation with boundaries on D3Q27: measured slower than SlabSimulation "
+                          "(0.97 vs 0.83 ms per step at 512 x 512 x 64, DESIGN.md section 5)", stacklevel=2)
         # A two-step workgroup holds a CU's LDS for its whole segment, and RCCL's copy kernel needs
         # LDS of its own: beside one long interior segment per CU it starts only when the first
         # workgroups retire.  Shorter segments let it in earlier: a quarter of the interior planes
