@@ -687,3 +687,8 @@ class TwoStepSlabSimulation(SlabSimulation):
             self._exchange(cur)()
         eng.stream_planes(cur, nxt, lo, hi)
         self.f, self.f_next = nxt, cur
+        if n - 1 >= 2 and self._signalled_ok() and eng.wait_timed_out():
+            # the polling wave gave up before the edge workgroups reported (it waits about a second): the
+            # exchange that followed sent planes that were not written yet
+            raise LettuceException("signalled slab launch: the communication stream timed out waiting for the "
+                                   "edge planes; the populations of this batch are not valid")
