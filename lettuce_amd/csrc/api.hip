@@ -553,9 +553,10 @@ constexpr int kManyMax = 8;        // == kManyMax of unit.inc
 // steps per many-step launch: a plan with an outlet recomputes one more ring of nodes around each tile
 int many_max(const lt_plan *p) { return kManyMax - ((p->masked && p->n_abb > 0) ? 1 : 0); }
 
-// Several steps per launch (lbm_many_kernel): 2-D, no masks, tiles of 8 x 8.  Every workgroup
-// recomputes a halo of K - 1 nodes around its tile, so this only pays while the grid is
-// launch-bound; "automatic" stops at 256 x 256 nodes (measured, tools/small_grid_bench.py).
+// Several steps per launch (lbm_many_kernel): 2-D, tiles of 8 x 8, with masks at most one outlet.  Every
+// workgroup recomputes a halo of K - 1 nodes around its tile (K with an outlet), so this only pays while the
+// grid is launch-bound; "automatic" stops at 256 x 256 nodes, 128 x 64 with masks (measured,
+// tools/small_grid_bench.py, tools/small_masked_bench.py).
 bool many_step_wanted(lt_plan *p) {
   if (p->many == 0 || p->desc.ghost_planes || p->unit.d != 2) return false;
   if (p->masked && p->n_abb > 1) return false;
