@@ -347,15 +347,23 @@ def main():
                 probe.setdefault(name, "unavailable on another rank")
                 cand = None
                 continue
-            best = None
+            best, failed = None, None
             for _ in range(2):                  # two batches of >= 60 steps, the faster one counts
                 barrier()
                 t0 = time.perf_counter()
-                cand(probe_steps)
+                try:
+                    cand(probe_steps)
+                except Exception as exc:        # e.g. the signalled driver's time-out: raised after the batch's
+                    failed = f"failed: {type(exc).__name__}: {str(exc)[:120]}"   # exchanges, so the ranks stay in step
                 barrier()
                 t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 best = float(t.item()) if best is None else min(best, float(t.item()))
+            if not all_ranks(failed is None):
+                probe[name] = failed or "failed on another rank"
+                cand = None
+                torch.cuda.empty_cache()
+                continue
             probe[name] = round(best / probe_steps * 1e3, 5)
             # keep only the final populations; candidates must not share the device while timed
             finals[name] = cand.local_f().clone()
