@@ -1241,47 +1241,52 @@ lbm_many_kernel(const KParams<T> p, const int K) {
       }
     }
   }
-  // an outlet node: index, node byte and no-streaming bits of the node next to it (fetched once)
+  // What the boundaries do to this node is the same in every step: its own boundary (bounce-back / equilibrium,
+  // index bidx) and, on the outlet's plane, the outlet (index out_slot) -- in index order.  Everything the
+  // plan's table says about them is fetched once; for an outlet node also the index, node byte and
+  // no-streaming bits of the node next to it.
+  int my_kind = 0, out_slot = 0, out_axis = 0, out_side = 1;
   unsigned nown = 0, nbits = 0;
   int nbidx = 0;
   if constexpr (MASKED) {
-    if (in_region && p.abb0_slot) {
-      for (int slot = 1; slot <= p.nb; ++slot)
-        if (p.bt->kind[slot] == kAbbOutlet) {
-          const int ax = p.bt->mem_axis[slot];
-          if ((ax == 0 ? g0 : g1) == p.bt->plane[slot]) {
-            const int ng0 = ax == 0 ? p.bt->nbr[slot] : g0, ng1 = ax == 1 ? p.bt->nbr[slot] : g1;
-            nown = (unsigned)ng1 * (unsigned)p.n0 + (unsigned)ng0;
-            const unsigned char nnd = p.node[nown];
-            nbidx = nnd & 0x7f;
-            nbits = (nnd & 0x80) ? p.nsm_bits[nown] : 0u;
+    if (in_region) {
+      if (bidx != 0) my_kind = p.bt->kind[bidx];
+      if (p.abb0_slot) {
+        for (int slot = 1; slot <= p.nb; ++slot)
+          if (p.bt->kind[slot] == kAbbOutlet) {
+            const int ax = p.bt->mem_axis[slot];
+            if ((ax == 0 ? g0 : g1) == p.bt->plane[slot]) {
+              out_slot = slot; out_axis = ax; out_side = p.bt->side[slot];
+              const int ng0 = ax == 0 ? p.bt->nbr[slot] : g0, ng1 = ax == 1 ? p.bt->nbr[slot] : g1;
+              nown = (unsigned)ng1 * (unsigned)p.n0 + (unsigned)ng0;
+              const unsigned char nnd = p.node[nown];
+              nbidx = nnd & 0x7f;
+              nbits = (nnd & 0x80) ? p.nsm_bits[nown] : 0u;
+            }
           }
-        }
+      }
     }
   }
-  // collision and the boundaries in index order; nbr(slot, rho, j): moments of the node next to an outlet node
+  // collision and the boundaries in index order; nbr(rho, j): moments of the node next to an outlet node
   auto collide_and_bound = [&](T (&f)[S::Q][1], auto &&nbr) {
     if constexpr (!MASKED) {
       collide(f);
     } else {
       if (bidx == 0) collide(f);
-      for (int slot = 1; slot <= p.nb; ++slot) {
-        const int kind = p.bt->kind[slot];
-        if (kind == kAbbOutlet) {
-          const int ax = p.bt->mem_axis[slot];
-          if ((ax == 0 ? g0 : g1) == p.bt->plane[slot]) {
-            T rn, jn[3];
-            nbr(slot, rn, jn);
-            abb_apply<T, S, 0, 1, 0>(p, slot, rn, jn, f);
-          }
-        } else if (bidx == slot) {
-          if (kind == kBounceBack) {
-            bounce_back<T, S, 1, 0>(f);
-          } else if (kind == kEquilibrium) {
-            static_for<S::Q>([&](auto qc) { f[decltype(qc)::value][0] = eqv[decltype(qc)::value]; });
-          }
-        }
+      auto outlet = [&]() {
+        T rn, jn[3];
+        nbr(rn, jn);
+        if (out_axis == 0) abb_apply_ax<T, S, 0, 0>(out_side, rn, jn, f);
+        else abb_apply_ax<T, S, 0, 1>(out_side, rn, jn, f);
+      };
+      // the outlet rewrites its whole plane, whatever the node's own index (apply_boundaries)
+      if (out_slot != 0 && (bidx == 0 || out_slot <= bidx)) outlet();
+      if (my_kind == kBounceBack) {
+        bounce_back<T, S, 1, 0>(f);
+      } else if (my_kind == kEquilibrium) {
+        static_for<S::Q>([&](auto qc) { f[decltype(qc)::value][0] = eqv[decltype(qc)::value]; });
       }
+      if (out_slot != 0 && bidx != 0 && out_slot > bidx) outlet();
     }
   };
   T f[S::Q][1];
@@ -1296,9 +1301,10 @@ lbm_many_kernel(const KParams<T> p, const int K) {
         if (bits & (1u << q)) f[q][0] = p.in[(long long)q * p.N + own];
       }
     });
-    collide_and_bound(f, [&](int slot, T &rn, T (&jn)[3]) {
-      const int ax = p.bt->mem_axis[slot], nb = p.bt->nbr[slot];
-      neighbour_moments<T, S, 0, true, true, COLL, 0>(p, ax == 0 ? nb : g0, ax == 1 ? nb : g1, 0, slot, rn, jn);
+    collide_and_bound(f, [&](T &rn, T (&jn)[3]) {
+      const int nb = p.bt->nbr[out_slot];
+      neighbour_moments<T, S, 0, true, true, COLL, 0>(p, out_axis == 0 ? nb : g0, out_axis == 1 ? nb : g1, 0, out_slot,
+                                                     rn, jn);
     });
   }
   for (int s = 1; s < K; ++s) {                 // f holds the state after step s
@@ -1321,10 +1327,9 @@ lbm_many_kernel(const KParams<T> p, const int K) {
           if (bits & (1u << q)) f[q][0] = lds[buf][q][i1 * G::R0 + i0];
         }
       });
-      collide_and_bound(f, [&](int slot, T &rn, T (&jn)[3]) {
+      collide_and_bound(f, [&](T &rn, T (&jn)[3]) {
         // the node next to this outlet node, inside the domain: its pull from the same LDS state
-        const int ax = p.bt->mem_axis[slot], side = p.bt->side[slot];
-        const int n0i = ax == 0 ? i0 - side : i0, n1i = ax == 1 ? i1 - side : i1;
+        const int n0i = out_axis == 0 ? i0 - out_side : i0, n1i = out_axis == 1 ? i1 - out_side : i1;
         T g[S::Q][1];
         static_for<S::Q>([&](auto qc) {
           constexpr int q = decltype(qc)::value;
@@ -1335,7 +1340,7 @@ lbm_many_kernel(const KParams<T> p, const int K) {
           }
         });
         moments<T, S, 0, 1, 0>(g, rn, jn);
-        lower_boundaries_on_moments<T, S, 0>(p, nbidx, slot, nown, rn, jn);
+        lower_boundaries_on_moments<T, S, 0>(p, nbidx, out_slot, nown, rn, jn);
       });
     }
   }
