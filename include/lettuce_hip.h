@@ -232,6 +232,12 @@ int lt_run(lt_plan *plan, void *buf_a_dev, void *buf_b_dev, double tau, int64_t 
  * leaves in the non-result buffer): n fused launches + one stream launch. */
 int lt_continue(lt_plan *plan, void *fstar_a_dev, void *buf_b_dev, double tau, int64_t n_steps,
                 void *stream, int32_t *result_in_b);
+/* on != 0: lt_run / lt_continue stop before their last (streaming) launch: *result_in_b then tells which
+ * buffer holds the POST-COLLISION populations of the last step, the other buffer is scratch; lt_stream of
+ * that buffer gives the post-streaming populations whenever somebody wants to see them, and lt_continue
+ * carries on from it without them.  A caller that advances in batches and looks at the populations only
+ * now and then (lettuce's Simulation with reporters every k steps) saves one pass over memory per batch. */
+int lt_plan_set_deferred_stream(lt_plan *plan, int32_t on);
 
 /* rho [*res] and u [d, *res] (either may be NULL) from post-streaming populations
  * (Flow.rho / Flow.j / Flow.u, lettuce/_flow.py:136-138,152-172). */

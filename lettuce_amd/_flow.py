@@ -101,15 +101,41 @@ class Flow(ABC):
         if self.initialize_fneq:
             self.f = initialize_f_neq(self)
 
+    # ---- the populations (lettuce/_flow.py:90) ---------------------------------------------------
+    # A plain attribute in the reference.  Here the engine may leave a batch of steps one streaming pass short
+    # (the post-collision populations f* of the last step are what the next batch continues from): the pass is
+    # done when somebody looks -- reading ``flow.f`` (or ``flow.f_next``) completes it, assigning drops it.
+    _pending = None      # callable that finishes the batch and returns (f, f_next), or None
+    _f = None
+
+    @property
+    def f(self) -> torch.Tensor:
+        if self._pending is not None:
+            self._finish_pending()
+        return self._f
+
+    @f.setter
+    def f(self, value: torch.Tensor):
+        self._pending = None
+        self._f = value
+
+    def _finish_pending(self):
+        finish, self._pending = self._pending, None
+        self._f, self._f_next = finish()
+
     # ---- double buffer used by the engine (lettuce/_flow.py:124-134) ------------------------
     @property
     def f_next(self) -> torch.Tensor:
+        if self._pending is not None:
+            self._finish_pending()
         if self._f_next is None:
             self._f_next = self.context.empty_tensor([self.stencil.q, *self.resolution])
         return self._f_next
 
     @f_next.setter
     def f_next(self, value: torch.Tensor):
+        if self._pending is not None:
+            self._finish_pending()
         self._f_next = value
 
     # ---- engine access for the moments -------------------------------------------------------

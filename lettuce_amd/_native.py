@@ -97,6 +97,7 @@ SYMBOLS = {
     "lt_stream_collide_twice_planes": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _i64, _vp]),
     "lt_stream_collide_twice_planes_packed": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _i64, _vp, _vp, _vp]),
     "lt_stream_collide_twice_edges": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i32, _vp, _vp, _vp]),
+    "lt_plan_set_deferred_stream": (ctypes.c_int, [_vp, _i32]),
     "lt_stream_collide_twice_slab": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _vp]),
     "lt_slab_wait_edges": (ctypes.c_int, [_vp, _vp]),
     "lt_slab_wait_timed_out": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _vp]),
@@ -381,9 +382,16 @@ class Plan:
             _ptr(pack_second), _stream_handle()))
 
     @_on_device
+    def set_deferred_stream(self, on: bool):
+        """run() then stops before its last streaming pass and returns (f*, scratch): the post-collision
+        populations of the last step and a buffer whose content is undefined (``stream(f*, scratch)``
+        gives the post-streaming populations)"""
+        self._check(self.lib.lt_plan_set_deferred_stream(self._handle, int(bool(on))))
+
     def run(self, a, b, tau, n_steps, from_fstar=False):
         """n whole steps; returns (result, other): ``result`` holds the new post-streaming
-        populations, ``other`` the post-collision populations of the last step."""
+        populations, ``other`` the post-collision populations of the last step (with
+        ``set_deferred_stream(True)``: see there)."""
         self._tensor_ok(a, self.f_shape); self._tensor_ok(b, self.f_shape)
         which = ctypes.c_int32(0)
         fn = self.lib.lt_continue if from_fstar else self.lib.lt_run

@@ -104,6 +104,7 @@ struct lt_plan {
   unsigned long long signal_target = 0;
   unsigned *signal_timed_out = nullptr;
   unsigned long long *signal_now = nullptr;   // where step() finds the counter for the launch being issued (or null)
+  int defer_stream = 0;      // lt_run / lt_continue stop before their last (streaming) pass (lt_plan_set_deferred_stream)
   char kernel_name[192];
   // launch-bound grids: a captured hipGraph of kGraphChunk fused steps (ping-pong returns to the
   // starting buffer), replayed on a plan-owned stream that is forked from / joined to the caller's
@@ -635,6 +636,10 @@ int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, 
   }
   if (p->ev_stop && twice == 0) (void)hipEventRecord(p->ev_stop, hs);
   }
+  if (p->defer_stream) {               // the caller streams when somebody wants to see the populations
+    *result_in_b = (cur == b) ? 1 : 0;
+    return LT_OK;
+  }
   rc = step(p, lt::kStreamOnly, cur, other, tau, 0, p->n2, stream);
   if (rc) return rc;
   *result_in_b = (other == b) ? 1 : 0;
@@ -974,6 +979,12 @@ int lt_plan_set_shift_policy(lt_plan *p, int32_t policy) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (policy < 0 || policy > 4) return fail(LT_ERR_INVALID, "shift policy %d", policy);
   p->shift = policy;
+  return LT_OK;
+}
+
+int lt_plan_set_deferred_stream(lt_plan *p, int32_t on) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  p->defer_stream = on ? 1 : 0;
   return LT_OK;
 }
 

@@ -220,6 +220,41 @@ def test_flow_modified_between_calls_restarts_from_f():
     np.testing.assert_allclose(flow.f.cpu().numpy(), ref.f.numpy(), rtol=0, atol=1e-13)
 
 
+def test_flow_f_is_completed_when_somebody_looks():
+    """The engine leaves a batch one streaming pass short and ``flow.f`` completes it on access (Flow.f): batches
+    that nobody looks at in between cost their fused launches only, and whatever the order of looking, assigning
+    and stepping, the populations are the reference's."""
+    c = gpu("f64")
+    g = golden("tgv2d_d2q9_bgk_32_f64")
+    res = [int(r) for r in g["resolution"]]
+
+    def fresh():
+        flow = lt.TaylorGreenVortex(c, res, float(g["reynolds"]), float(g["mach"]), lt.D2Q9())
+        return flow, lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])
+    flow, sim = fresh()
+    sim(4)
+    assert flow._pending is not None                 # not streamed yet
+    sim(3); sim(3)                                   # carries on from the post-collision populations
+    assert flow._pending is not None
+    looked = flow.f                                  # one streaming pass, now
+    assert flow._pending is None and flow.f is looked
+    flow2, sim2 = fresh()
+    sim2(10)
+    assert torch.equal(flow2.f, looked)
+    np.testing.assert_allclose(looked.cpu().numpy(), g["f10"], rtol=0, atol=1e-13)
+    # looking in between changes nothing; neither does reading f_next or the moments
+    flow3, sim3 = fresh()
+    sim3(4); _ = flow3.rho(); sim3(3); _ = flow3.f_next; sim3(3)
+    assert torch.equal(flow3.f, looked)
+    # an assignment while a pass is pending replaces the state (the pending pass is dropped)
+    flow4, sim4 = fresh()
+    sim4(5)
+    flow4.f = looked.clone()
+    assert flow4._pending is None
+    sim4(2); sim2(2)
+    assert torch.equal(flow4.f, flow2.f)
+
+
 def test_collision_callable_and_moments_use_engine():
     g = golden("operators_d3q27_f32")
     flow = lt.TaylorGreenVortex(gpu(), list(g["f"].shape[1:]), 50, 0.1, lt.D3Q27())
