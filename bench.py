@@ -498,7 +498,9 @@ def main():
                             "batch): populations read once + written once per launch / time; "
                             "algorithmic_update_GBps counts 152 B per node and update"}
 
-    passes = "1 collide + (K-1) fused stream-collide + 1 stream"
+    passes = ("K fused stream-collide steps per batch, continuing from the post-collision populations (ghost planes "
+              "exchanged) of the batch before; the streaming pass that presents the populations in lettuce's "
+              "post-streaming convention runs when they are read (not inside the timed batches)")
     if roofline and roofline.get("lattice_updates_per_node_per_launch", 0) == 2:
         # the timed call continues from the post-collision state the warm-up call left (lt_continue)
         passes = ("K fused stream-collide steps (K streamings, K collisions) as K/2 two-step launches (+1 single when K "

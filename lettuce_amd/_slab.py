@@ -288,6 +288,63 @@ class SlabSimulation:
     def _message_blocks(self, stencil) -> int:
         return len(self.up)
 
+    # ---- the populations -------------------------------------------------------------------------
+    # ``f`` holds post-streaming populations (lettuce's convention) whenever somebody looks; between batches
+    # the driver keeps the post-collision populations of the last step (ghost planes exchanged) and carries on
+    # from them, and the streaming pass that presents ``f`` runs when ``f`` / ``f_next`` are read (local_f,
+    # gather_f, the observables).  A batch that nobody looks at costs its fused steps only.
+    _pending = None          # (f*, scratch) while ``f`` is one streaming pass short
+    _carry = None            # version of ``_f`` when ``_f_next`` held the f* it was streamed from
+    _f = None
+    _f_next = None
+
+    @property
+    def f(self) -> torch.Tensor:
+        if self._pending is not None:
+            self._present()
+        return self._f
+
+    @f.setter
+    def f(self, value):
+        self._pending, self._carry = None, None
+        self._f = value
+
+    @property
+    def f_next(self) -> torch.Tensor:
+        if self._pending is not None:
+            self._present()
+        return self._f_next
+
+    @f_next.setter
+    def f_next(self, value):
+        if self._pending is not None:
+            self._present()
+        self._carry = None
+        self._f_next = value
+
+    def _present(self):
+        from ._simulation import _version
+        (cur, nxt), self._pending = self._pending, None
+        self.engine.stream_planes(cur, nxt, self.lo, self.hi)
+        self._f, self._f_next = nxt, cur
+        self._carry = _version(nxt)
+
+    def _start_batch(self, tau):
+        """(f*, scratch, fused steps already owed): the post-collision populations to carry on from -- kept from
+        the batch before, or one collide pass + exchange away from ``f``"""
+        from ._simulation import _version
+        if self._pending is not None:
+            (cur, nxt), self._pending = self._pending, None
+            return cur, nxt, True
+        if self._carry is not None and self._carry == _version(self._f):
+            self._carry = None
+            return self._f_next, self._f, True
+        self._carry = None
+        cur, nxt = self._f, self._f_next
+        self.engine.collide_planes(cur, nxt, tau, self.lo, self.hi)
+        self._exchange(nxt)()
+        return nxt, cur, False
+
     # ---- views ---------------------------------------------------------------------------------
     def local_f(self) -> torch.Tensor:
         """this rank's populations as a ``[q, nx, ny, nz_local]`` view (reference axis order)"""
@@ -407,18 +464,14 @@ class SlabSimulation:
             finish()
 
     def _advance(self, n: int):
-        """n whole steps: collide, exchange, (n-1) x fused, stream -- as lt_run does on one GPU."""
+        """n whole steps: (collide, exchange,) n - 1 or -- carrying on from the batch before -- n fused steps; the
+        streaming pass that completes the last one runs when ``f`` is read (as Flow.f does on one GPU)."""
         tau = float(self._tau(self.flow))
-        eng, nzl = self.engine, self.nzl
-        cur, nxt = self.f, self.f_next
-        eng.collide_planes(cur, nxt, tau, 1, nzl + 1)
-        cur, nxt = nxt, cur
-        self._exchange(cur)()
-        for _ in range(n - 1):
+        cur, nxt, carried = self._start_batch(tau)
+        for _ in range(n if carried else n - 1):
             self._fused_step(cur, nxt, tau)
             cur, nxt = nxt, cur
-        eng.stream_planes(cur, nxt, 1, nzl + 1)
-        self.f, self.f_next = nxt, cur
+        self._pending = (cur, nxt)                    # streamed when somebody looks (``f``)
 
     def _next_report(self, limit):
         k = limit
@@ -668,15 +721,14 @@ class TwoStepSlabSimulation(SlabSimulation):
             self._exchange(nxt)()
 
     def _advance(self, n: int):
-        """n whole steps: collide, exchange, floor((n-1)/2) double steps (+ one single fused step
-        when n-1 is odd), stream."""
+        """n whole steps: (collide, exchange,) the n - 1 or -- carrying on from the batch before -- n fused steps
+        as double steps (+ one single fused step when their number is odd); the streaming pass that completes
+        the last one runs when ``f`` is read."""
         tau = float(self._tau(self.flow))
         eng, lo, hi = self.engine, self.lo, self.hi
-        cur, nxt = self.f, self.f_next
-        eng.collide_planes(cur, nxt, tau, lo, hi)
-        cur, nxt = nxt, cur
-        self._exchange(cur)()
-        fused = n - 1
+        cur, nxt, carried = self._start_batch(tau)
+        fused = n if carried else n - 1
+        signalled_steps = fused >= 2
         while fused >= 2:
             self._double_step(cur, nxt, tau)
             cur, nxt = nxt, cur
@@ -685,9 +737,8 @@ class TwoStepSlabSimulation(SlabSimulation):
             eng.stream_collide_planes(cur, nxt, tau, lo, hi)
             cur, nxt = nxt, cur
             self._exchange(cur)()
-        eng.stream_planes(cur, nxt, lo, hi)
-        self.f, self.f_next = nxt, cur
-        if n - 1 >= 2 and self._signalled_ok() and eng.wait_timed_out():
+        self._pending = (cur, nxt)                    # streamed when somebody looks (``f``)
+        if signalled_steps and self._signalled_ok() and eng.wait_timed_out():
             # the polling wave gave up before the edge workgroups reported (it waits about a second): the
             # exchange that followed sent planes that were not written yet
             raise LettuceException("signalled slab launch: the communication stream timed out waiting for the "
