@@ -273,6 +273,8 @@ def main():
         nodes_per_rank = n ** 3
         kernel = sim._native.plan.kernel_name()
         sim(args.warmup)
+        # the plain copy rate of this device (roofline.copy_ceiling_GBps) is measured before the timed batches
+        ceiling = copy_ceiling(device)
         pre_timed = None if args.no_verify else flow.f.clone()   # lettuce's convention: post-streaming
         sim._native.fused_events = (start, end)
         step = sim
@@ -465,7 +467,6 @@ def main():
                             "HBM rate)" + ("; the launch performs two lattice updates per node with the intermediate "
                                            "state in LDS, algorithmic_update_GBps counts 152 B per node and update"
                                            if paired else ""))
-        ceiling = copy_ceiling(device)
         roofline["copy_ceiling_GBps"] = round(ceiling, 1)
         roofline["frac_of_copy_ceiling"] = round(achieved / ceiling, 4)
         # ---- self-check of the timed result (untimed) ------------------------------------------
@@ -521,7 +522,9 @@ def main():
                        "global_resolution": global_res, "parallelism": parallelism,
                        "passes_per_batch": passes},
             "batches_ms_per_step": [round(t / args.steps * 1e3, 5) for t in batch_s],
-            "timing": f"median of {len(batch_s)} timed batches of {args.steps} steps",
+            "timing": f"median of {len(batch_s)} timed batches of {args.steps} steps"
+                      + ("" if distributed else "; the device's plain copy rate (roofline.copy_ceiling_GBps) is measured "
+                         "between the warm-up steps and the timed batches"),
             "roofline": roofline,
         }
         if present_ms is not None:
