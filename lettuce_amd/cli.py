@@ -62,7 +62,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="lettuce_amd")
     ap.add_argument("--cuda", dest="cuda", action="store_true", default=True)
     ap.add_argument("--no-cuda", dest="cuda", action="store_false")
-    ap.add_argument("-p", "--precision", choices=["half", "single", "double"], default="single")
+    ap.add_argument("-p", "--precision", choices=["half", "single", "double"], default="double")   # lettuce/cli.py:33-37
     ap.add_argument("--use-native", dest="use_native", action="store_true", default=True)
     ap.add_argument("--use-no-native", dest="use_native", action="store_false")
     sub = ap.add_subparsers(dest="command", required=True)
