@@ -451,6 +451,14 @@ def test_convergence_order_tgv2d():
     assert 0.8 < 2 ** order_p / 2 < 1.2, (errors, order_p)
 
 
+def test_cli_convergence_command_with_its_defaults(capsys):
+    """`python -m lettuce_amd convergence` as the reference's CLI runs it (double precision, 16^2 ... 256^2; the
+    last grids go through the several-steps-per-launch kernel): exit code 0, i.e. orders within 0.1 of 2 and 1."""
+    from lettuce_amd.cli import main
+    assert main(["convergence"]) == 0
+    assert "FAILED" not in capsys.readouterr().out
+
+
 def test_non_native_mode_on_a_gpu_device():
     """Context('cuda', use_native=False): the reference's whole-field torch expressions on device
     tensors (per-node contractions evaluated without BLAS) still match the reference vectors."""
