@@ -335,7 +335,7 @@ int lt_stream_collide_twice(lt_plan *plan, const void *f_dev, void *out_dev, dou
  * one anti-bounce-back outlet, for which one more ring of nodes is recomputed: n_steps <= 7);
  * LT_ERR_UNSUPPORTED otherwise.
  * lt_plan_set_many_step: lt_run / lt_continue use it for their fused steps: -1 = automatic (grids up
- * to 256 x 256 nodes, with masks up to 128 x 64; BGK / no collision, where it is bit-identical to the
+ * to 256 x 256 nodes, with masks up to 256 x 128; BGK / no collision, where it is bit-identical to the
  * one-step kernel),
  * 0 = never, 1 = whenever supported. */
 int lt_stream_collide_many(lt_plan *plan, const void *f_dev, void *out_dev, double tau, int32_t n_steps,

@@ -556,7 +556,7 @@ int many_max(const lt_plan *p) { return kManyMax - ((p->masked && p->n_abb > 0) 
 
 // Several steps per launch (lbm_many_kernel): 2-D, tiles of 8 x 8, with masks at most one outlet.  Every
 // workgroup recomputes a halo of K - 1 nodes around its tile (K with an outlet), so this only pays while the
-// grid is launch-bound; "automatic" stops at 256 x 256 nodes, 128 x 64 with masks (measured,
+// grid is launch-bound; "automatic" stops at 256 x 256 nodes, 256 x 128 with masks (measured,
 // tools/small_grid_bench.py, tools/small_masked_bench.py).
 bool many_step_wanted(lt_plan *p) {
   if (p->many == 0 || p->desc.ghost_planes || p->unit.d != 2) return false;
@@ -572,9 +572,10 @@ bool many_step_wanted(lt_plan *p) {
   // result of n steps does not depend on how the caller splits them into batches (KBC agrees at
   // rounding level only)
   if (p->desc.collision == LT_COLLISION_KBC) return false;
-  // with masks the launch is bound by its own latency chain (node bytes, boundary table, seven barriers) and
-  // recomputes a wider ring: 128 x 64 nodes 4.1 -> 2.7 us per step, 256 x 128 4.5 -> 4.9 (tools/small_masked_bench.py)
-  if (p->masked) return p->N <= 128ll * 64ll;
+  // with masks the launch is bound by its own latency chain (node byte, boundary values, a barrier per step) and
+  // recomputes a wider ring: 128 x 64 nodes 4.2 -> 2.4 us per step, 128 x 128 4.3 -> 2.5, 256 x 128 4.5 -> 3.3,
+  // 256 x 256 5.6 -> 5.7 (tools/small_masked_bench.py, fp64)
+  if (p->masked) return p->N <= 256ll * 128ll;
   return p->N <= 256ll * 256ll;
 }
 
