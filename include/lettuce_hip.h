@@ -202,6 +202,18 @@ int lt_stream_collide_twice_planes_packed(lt_plan *plan, const void *f_dev, void
 int lt_stream_collide_twice_edges(lt_plan *plan, const void *f_dev, void *out_dev, double tau,
                                   int32_t edge_planes, void *pack_lower_dev, void *pack_upper_dev,
                                   void *stream);
+/* The same edge launch fed straight from the receive buffers: wherever its pull reaches beyond a cut it reads the
+ * halo message that arrived from the rank below (recv_lower_dev) / above (recv_upper_dev) -- layout of
+ * lt_slab_pack_two_step -- instead of the ghost planes of f_dev, which need not be filled (no
+ * lt_slab_unpack_two_step); and it writes both outgoing messages.  With lt_stream_collide_twice_planes for the
+ * planes [2 + edge_planes, n2 - 2 - edge_planes), which never reads a ghost plane, a double step of a slab is two
+ * launches on one stream and one exchange that starts after the first of them: no pack launch, no unpack launch,
+ * no launches competing for the compute units.  Both recv pointers NULL: the ghost planes of f_dev are read (the
+ * first double step after a collide pass, whose exchange ended in them).  Plans without masks. */
+int lt_stream_collide_twice_edges_direct(lt_plan *plan, const void *f_dev, void *out_dev, double tau,
+                                         int32_t edge_planes, const void *recv_lower_dev,
+                                         const void *recv_upper_dev, void *pack_lower_dev, void *pack_upper_dev,
+                                         void *stream);
 /* The whole slab -- output planes [2, n2 - 2) -- in ONE launch that releases the exchange while it runs (plans
  * without masks).  The workgroups that produce the two planes next to each cut start first; each adds 1 to a
  * counter of the plan when those planes are in memory.  lt_slab_wait_edges enqueues, on ANOTHER stream, one
@@ -217,6 +229,12 @@ int lt_slab_two_step_message_blocks(lt_plan *plan, int32_t *blocks_out);
 /* LT_OK when lt_stream_collide_twice / _planes has a kernel for this plan as it stands (lattice, dtype,
  * collision, grid extents, masks); LT_ERR_UNSUPPORTED (and the reason in lt_last_error) otherwise. */
 int lt_plan_two_step_admitted(lt_plan *plan);
+/* Descriptor-only query (no device, no plan): the tile of the two-step kernels for this stencil / dtype
+ * (tile_width x tile_rows nodes; rows = 0: no kernel) and whether a field of these extents stays within the
+ * kernels' 32-bit byte offsets (masked != 0: the whole field, q * nodes * sizeof(scalar) < 4 GiB; else one plane).
+ * lt_run / lt_plan_two_step_admitted apply the same rule, so a plan beyond it keeps the one-step kernel. */
+int lt_two_step_limits(const lt_plan_desc *desc, int32_t masked, int32_t *tile_width, int32_t *tile_rows,
+                       int32_t *addressable);
 int lt_slab_pack_two_step(lt_plan *plan, const void *f_dev, int32_t side, void *buf_dev, void *stream);
 int lt_slab_unpack_two_step(lt_plan *plan, void *f_dev, int32_t side, const void *buf_dev, void *stream);
 
@@ -345,6 +363,36 @@ int lt_plan_set_many_step(lt_plan *plan, int32_t mode);
  * mode -1 = automatic, 0 = never, 1 = whenever supported.  planes_per_workgroup: segment length of
  * the sweep along the slowest axis (0 = automatic). */
 int lt_plan_set_two_step(lt_plan *plan, int32_t mode, int32_t planes_per_workgroup);
+/* Population stride.  By default a population buffer is dense: population q starts q * nodes elements after
+ * population 0 (the reference's [q, *res] tensor, lettuce/_flow.py:90).  With the q populations a power of two
+ * apart (256^3 fp32: exactly 64 MiB) the q read and q write streams of a node meet in the same memory channels;
+ * buffers the CALLER owns and the reference never sees -- the slab tensors of a multi-GPU rank -- may therefore
+ * be padded: every population buffer handed to this plan's entry points (steps, pack / unpack, reductions,
+ * lt_macroscopic) then has `stride_elements` (>= nodes incl. ghost planes, a multiple of 256 bytes) between
+ * consecutive populations; 0 = dense again.  Per-node boundary fields and masks stay dense. */
+int lt_plan_set_population_stride(lt_plan *plan, int64_t stride_elements);
+int lt_plan_population_stride(lt_plan *plan, int64_t *stride_elements_out);
+/* Resident populations: the engine's own padded ping-pong buffers for the fused steps of a periodic plan, so that
+ * the caller's tensors stay the reference's plain [q, *res] (lettuce/_flow.py:90,124-134,226-236) and are touched
+ * only when somebody looks:
+ *   lt_resident_load     f* <- B(C(f)): one collide pass from the caller's post-streaming populations (the
+ *                        reference's flow.f) into the resident buffer;
+ *   lt_resident_advance  n fused stream-collide steps on the resident f* (lt_run's fused section: two updates per
+ *                        launch where the kernel exists, several on small 2-D grids; lt_plan_set_fused_events and
+ *                        lt_plan_last_run_info apply);
+ *   lt_resident_store    out <- S(f*): the streaming pass that presents the populations in lettuce's convention;
+ *                        the resident state stays valid, a later lt_resident_advance carries on from it;
+ *   lt_resident_free     releases the two buffers (lt_plan_destroy does too).
+ * k whole lettuce steps from flow.f are load + advance(k - 1) (+ store when flow.f is read); a batch that carries
+ * on is advance(k).  lt_plan_set_resident: mode -1 = automatic (lt_resident_enabled reports 1 when the populations
+ * exceed the caches), 0 = off, 1 = on; pad_elements = distance added between populations, -1 = the engine's choice.
+ * lt_run / lt_continue keep working on caller-owned dense buffers whatever the mode. */
+int lt_plan_set_resident(lt_plan *plan, int32_t mode, int64_t pad_elements);
+int lt_resident_enabled(lt_plan *plan, int32_t *enabled_out, int64_t *stride_elements_out);
+int lt_resident_load(lt_plan *plan, const void *f_dev, double tau, void *stream);
+int lt_resident_advance(lt_plan *plan, double tau, int64_t n_steps, void *stream);
+int lt_resident_store(lt_plan *plan, void *out_dev, void *stream);
+int lt_resident_free(lt_plan *plan);
 /* Measurement hooks.  With two hipEvent_t set, lt_run / lt_continue record them on the launch stream
  * around their fused launches (around the two-step launches when there are any, else around the
  * single-step ones, or around the many-step launches); null, null removes them.

@@ -116,7 +116,13 @@ class Flow(ABC):
 
     @f.setter
     def f(self, value: torch.Tensor):
-        self._pending = None
+        if self._pending is not None:
+            # the batch that was one pass short is abandoned: let its owner release the two population buffers
+            # it holds for that pass (the engine's stepper would otherwise keep them until its next batch)
+            drop = getattr(self._pending, "drop", None)
+            self._pending = None
+            if drop is not None:
+                drop()
         self._f = value
 
     def _finish_pending(self):

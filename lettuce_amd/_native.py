@@ -97,14 +97,25 @@ SYMBOLS = {
     "lt_stream_collide_twice_planes": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _i64, _vp]),
     "lt_stream_collide_twice_planes_packed": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _i64, _vp, _vp, _vp]),
     "lt_stream_collide_twice_edges": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i32, _vp, _vp, _vp]),
+    "lt_stream_collide_twice_edges_direct": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i32, _vp, _vp, _vp, _vp, _vp]),
     "lt_plan_set_deferred_stream": (ctypes.c_int, [_vp, _i32]),
     "lt_stream_collide_twice_slab": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _vp]),
     "lt_slab_wait_edges": (ctypes.c_int, [_vp, _vp]),
     "lt_slab_wait_timed_out": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _vp]),
     "lt_slab_two_step_message_blocks": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
     "lt_plan_two_step_admitted": (ctypes.c_int, [_vp]),
+    "lt_two_step_limits": (ctypes.c_int, [ctypes.POINTER(_PlanDesc), _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32),
+                                          ctypes.POINTER(_i32)]),
     "lt_slab_pack_two_step": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "lt_slab_unpack_two_step": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
+    "lt_plan_set_population_stride": (ctypes.c_int, [_vp, _i64]),
+    "lt_plan_population_stride": (ctypes.c_int, [_vp, ctypes.POINTER(_i64)]),
+    "lt_plan_set_resident": (ctypes.c_int, [_vp, _i32, _i64]),
+    "lt_resident_enabled": (ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i64)]),
+    "lt_resident_load": (ctypes.c_int, [_vp, _vp, _dbl, _vp]),
+    "lt_resident_advance": (ctypes.c_int, [_vp, _dbl, _i64, _vp]),
+    "lt_resident_store": (ctypes.c_int, [_vp, _vp, _vp]),
+    "lt_resident_free": (ctypes.c_int, [_vp]),
     "lt_plan_set_fused_events": (ctypes.c_int, [_vp, _vp, _vp]),
     "lt_plan_last_run_info": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                              ctypes.POINTER(ctypes.c_int64)]),
@@ -215,6 +226,7 @@ class Plan:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self._keepalive = {}            # boundary index -> field tensor the engine holds a pointer to
+        self.pop_stride = 0             # elements between populations of the caller's buffers (0 = dense)
         desc = _PlanDesc()
         desc.abi_version = LT_ABI_VERSION
         desc.stencil = STENCIL_IDS[stencil]
@@ -266,7 +278,9 @@ class Plan:
         if t.dtype != self.dtype:
             raise NativeEngineError(f"tensor dtype {t.dtype}, plan dtype {self.dtype}")
         if not t.is_contiguous():
-            raise NativeEngineError("population tensors must be contiguous")
+            stride = getattr(self, "pop_stride", 0)
+            if not (stride and t.dim() > 1 and t.stride(0) == stride and t[0].is_contiguous()):
+                raise NativeEngineError("population tensors must be contiguous (or carry the plan's population stride)")
         if shape is not None and list(t.shape) != list(shape):
             raise NativeEngineError(f"tensor shape {list(t.shape)}, expected {list(shape)}")
 
@@ -388,6 +402,7 @@ class Plan:
         gives the post-streaming populations)"""
         self._check(self.lib.lt_plan_set_deferred_stream(self._handle, int(bool(on))))
 
+    @_on_device
     def run(self, a, b, tau, n_steps, from_fstar=False):
         """n whole steps; returns (result, other): ``result`` holds the new post-streaming
         populations, ``other`` the post-collision populations of the last step (with
@@ -398,6 +413,59 @@ class Plan:
         self._check(fn(self._handle, _ptr(a), _ptr(b), float(tau), int(n_steps), _stream_handle(),
                        ctypes.byref(which)))
         return (b, a) if which.value else (a, b)
+
+    # ------------------------------------------------------------------ population stride / resident state
+    def set_population_stride(self, stride: int = 0):
+        """every population buffer given to this plan has ``stride`` elements between consecutive populations
+        (0 = dense); see ``empty_populations``"""
+        self._check(self.lib.lt_plan_set_population_stride(self._handle, int(stride)))
+        self.pop_stride = int(stride)
+
+    def empty_populations(self) -> torch.Tensor:
+        """an uninitialised population tensor of this plan's shape and population stride (a strided view of one
+        allocation when the plan is padded)"""
+        stride = getattr(self, "pop_stride", 0)
+        shape = self.f_shape
+        with torch.cuda.device(self.device):
+            if not stride:
+                return torch.empty(shape, dtype=self.dtype, device=self.device)
+            flat = torch.empty(self.q * stride, dtype=self.dtype, device=self.device)
+        inner = torch.empty(shape[1:], device="meta").stride()
+        return flat.as_strided(shape, (stride,) + tuple(inner))
+
+    def populations_like(self, f: torch.Tensor) -> torch.Tensor:
+        """``f`` copied into a tensor with this plan's population stride"""
+        out = self.empty_populations()
+        out.copy_(f)
+        return out
+
+    def set_resident(self, mode: int = -1, pad_elements: int = -1):
+        """engine-owned padded buffers for the fused steps: -1 automatic, 0 off, 1 on"""
+        self._check(self.lib.lt_plan_set_resident(self._handle, int(mode), int(pad_elements)))
+
+    def resident_enabled(self):
+        """(enabled, stride in elements of the resident buffers)"""
+        on, stride = ctypes.c_int32(0), ctypes.c_int64(0)
+        self._check(self.lib.lt_resident_enabled(self._handle, ctypes.byref(on), ctypes.byref(stride)))
+        return bool(on.value), int(stride.value)
+
+    @_on_device
+    def resident_load(self, f, tau):
+        self._tensor_ok(f, self.f_shape)
+        self._check(self.lib.lt_resident_load(self._handle, _ptr(f), float(tau), _stream_handle()))
+
+    @_on_device
+    def resident_advance(self, tau, n_steps):
+        self._check(self.lib.lt_resident_advance(self._handle, float(tau), int(n_steps), _stream_handle()))
+
+    @_on_device
+    def resident_store(self, out):
+        self._tensor_ok(out, self.f_shape)
+        self._check(self.lib.lt_resident_store(self._handle, _ptr(out), _stream_handle()))
+        return out
+
+    def resident_free(self):
+        self._check(self.lib.lt_resident_free(self._handle))
 
     @_on_device
     def macroscopic(self, f, want_rho=True, want_u=True):
@@ -500,6 +568,7 @@ class Plan:
     def set_tuning(self, cache_policy: int = -1, wide: bool = False):
         self._check(self.lib.lt_plan_set_tuning(self._handle, int(cache_policy), int(bool(wide))))
 
+    @_on_device
     def set_fused_events(self, start=None, stop=None):
         """torch.cuda.Event pair recorded by lt_run around its fused launches (None, None: off)"""
         if start is None:
@@ -559,14 +628,24 @@ class Plan:
             _stream_handle()))
 
     @_on_device
+    def stream_collide_twice_edges_direct(self, f, out, tau, edge_planes, recv_lower, recv_upper, pack_lower, pack_upper):
+        """the two edges of the slab in one launch that reads the planes beyond the cuts from the received halo
+        messages (no unpack) and writes both outgoing messages (no pack)"""
+        self._check(self.lib.lt_stream_collide_twice_edges_direct(
+            self._handle, _ptr(f), _ptr(out), float(tau), int(edge_planes), _ptr(recv_lower), _ptr(recv_upper),
+            _ptr(pack_lower), _ptr(pack_upper), _stream_handle()))
+
+    @_on_device
     def stream_collide_twice_slab(self, f, out, tau):
         """all interior planes in one launch whose edge workgroups run first and count themselves done on a
         device counter (``wait_edges`` on another stream waits for it)"""
         self._check(self.lib.lt_stream_collide_twice_slab(self._handle, _ptr(f), _ptr(out), float(tau), _stream_handle()))
 
+    @_on_device
     def wait_edges(self):
         self._check(self.lib.lt_slab_wait_edges(self._handle, _stream_handle()))
 
+    @_on_device
     def wait_timed_out(self) -> bool:
         flag = ctypes.c_int32(0)
         self._check(self.lib.lt_slab_wait_timed_out(self._handle, ctypes.byref(flag), _stream_handle()))
@@ -583,6 +662,7 @@ class Plan:
             return None
         return self.lib.lt_last_error().decode()
 
+    @_on_device
     def pack_two_step(self, f, side, buf):
         self._check(self.lib.lt_slab_pack_two_step(self._handle, _ptr(f), int(side), _ptr(buf), _stream_handle()))
 

@@ -189,6 +189,8 @@ class _NativeStepper:
         self._sync_masks()
         self._sync_boundaries()
         tau = float(self.collision.tau(flow))
+        if self.plan.resident_enabled()[0]:
+            return self._batch_resident(k, tau)
         changed = self._carry is None                         # first batch, or masks / boundaries were replaced
         pending = flow._pending is not None and self._lazy is not None
         if pending:
@@ -218,6 +220,50 @@ class _NativeStepper:
             self._lazy = None
             self._carry = (_version(result), _version(fstar), tau)
             return result, fstar
+
+        def drop():                                           # flow.f was assigned while the pass was pending
+            self._lazy = None
+            self._carry = None
+        finish.drop = drop
+        flow._pending = finish
+
+    def _batch_resident(self, k: int, tau: float):
+        """The same batch with the post-collision populations in the ENGINE's padded ping-pong buffers
+        (``lt_resident_*``): ``flow.f`` / ``flow.f_next`` stay the reference's plain ``[q, *res]`` tensors
+        (lettuce/_flow.py:90,124-134) and are written only by the pass that presents the populations when somebody
+        looks.  k steps from ``flow.f`` are load (collide) + k - 1 fused steps; a batch that carries on -- nobody
+        looked, or what was shown has not been touched since -- is k fused steps."""
+        flow, plan = self.sim.flow, self.plan
+        if self.fused_events is not None:
+            plan.set_fused_events(*self.fused_events)
+        try:
+            if flow._pending is not None and self._carry == ("resident-pending", tau):
+                plan.resident_advance(tau, k)
+            else:
+                f, nxt = self._state_buffers()                # reading flow.f completes a pending batch
+                if self._carry == ("resident", _version(f), tau):
+                    plan.resident_advance(tau, k)             # what was shown is still what the engine holds
+                else:
+                    plan.resident_load(f, tau)
+                    plan.resident_advance(tau, k - 1)
+                self._lazy = (f, nxt, None)                   # the two dense buffers of the flow
+        finally:
+            if self.fused_events is not None:
+                plan.set_fused_events(None, None)
+        self._carry = ("resident-pending", tau)
+        flow._f, flow._f_next = None, None                    # nobody may see the buffers until the pass is done
+
+        def finish():
+            f, nxt, _ = self._lazy
+            result = plan.resident_store(nxt)                 # the buffer shown last keeps its content
+            self._lazy = None
+            self._carry = ("resident", _version(result), tau)
+            return result, f
+
+        def drop():                                           # flow.f was assigned while the pass was pending
+            self._lazy = None
+            self._carry = None
+        finish.drop = drop
         flow._pending = finish
 
     def single_step(self, *_, **__):

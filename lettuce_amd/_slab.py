@@ -190,6 +190,10 @@ class SlabSimulation:
 
     GHOST = 1            # ghost planes per side
     ONE_STREAM_WINDOWS = False
+    # elements between the end of one population and the start of the next in the slab tensors (HIP engine only).
+    # The one-step kernels stream best from dense populations (tools/pad_sweep_probe.py: padding costs them 2-4 %),
+    # the two-step kernels from padded ones: TwoStepSlabSimulation overrides this.
+    POPULATION_PAD = 0
 
     def __init__(self, flow, collision, slab: ZSlab, reporter=None, engine=None, group=None,
                  overlap: bool = True, comm_priority: int = -1, transport: str = "rccl"):
@@ -255,8 +259,20 @@ class SlabSimulation:
         self.engine = engine
         # [q, nx, ny, nzl + 2g] incl. the ghost planes -> [q, nzl + 2g, ny, nx]
         core = flow.f[..., h - g:h + nzl + g]
-        self.f = core.permute(0, 3, 2, 1).contiguous()
-        self.f_next = torch.empty_like(self.f)
+        # The slab tensors are this driver's own (the reference never sees them), so the populations need not be
+        # dense: with the HIP engine they are ``pad`` elements further apart than their size (one allocation,
+        # strided views), which keeps the q streams of a node out of each other's memory channels
+        # (lt_plan_set_population_stride; LT_SLAB_PAD overrides, 0 = dense)
+        pad = int(os.environ.get("LT_SLAB_PAD", str(self.POPULATION_PAD)))
+        if pad > 0 and hasattr(engine, "set_population_stride") and core.is_cuda:
+            nodes = (nzl + 2 * g) * ny * nx
+            unit = 256 // core.element_size()
+            engine.set_population_stride(-(-(nodes + pad) // unit) * unit)
+            self.f = engine.populations_like(core.permute(0, 3, 2, 1))
+            self.f_next = engine.empty_populations()
+        else:
+            self.f = core.permute(0, 3, 2, 1).contiguous()
+            self.f_next = torch.empty_like(self.f)
         flow.f = None                       # the extended slab is not needed any more
         flow._f_next = None
         # one contiguous message per direction: [n_crossing, ny, nx]
@@ -327,7 +343,7 @@ class SlabSimulation:
         (cur, nxt), self._pending = self._pending, None
         self.engine.stream_planes(cur, nxt, self.lo, self.hi)
         self._f, self._f_next = nxt, cur
-        self._carry = _version(nxt)
+        self._carry = (_version(nxt), _version(cur))      # both buffers: f* lives in the second one
 
     def _start_batch(self, tau):
         """(f*, scratch, fused steps already owed): the post-collision populations to carry on from -- kept from
@@ -336,7 +352,7 @@ class SlabSimulation:
         if self._pending is not None:
             (cur, nxt), self._pending = self._pending, None
             return cur, nxt, True
-        if self._carry is not None and self._carry == _version(self._f):
+        if self._carry is not None and self._carry == (_version(self._f), _version(self._f_next)):
             self._carry = None
             return self._f_next, self._f, True
         self._carry = None
@@ -548,13 +564,14 @@ class TwoStepSlabSimulation(SlabSimulation):
     """
 
     GHOST = 2
+    POPULATION_PAD = 32832       # 128 KiB + 256 B in fp32: the engine's choice for its own buffers too
     # With windows the exchange could ride on the compute stream (stores + signal before the interior
     # launch, wait + unpack after it); on one GPU that is 1.5 % faster, but across xGMI the pack
     # launch takes as long as the transfer and would delay the interior launch: two streams.
     ONE_STREAM_WINDOWS = False
 
     def __init__(self, flow, collision, slab: ZSlab, fused_remote_pack: Optional[bool] = None,
-                 signalled: Optional[bool] = None, **kwargs):
+                 signalled: Optional[bool] = None, direct: Optional[bool] = None, **kwargs):
         """``fused_remote_pack`` (window transport only): True = the edge launches store the halo
         message into the neighbour's window themselves and the whole exchange rides on the compute
         stream; False (default, see ``_edges``) = a separate pack launch on the communication
@@ -569,6 +586,17 @@ class TwoStepSlabSimulation(SlabSimulation):
         if signalled is None:
             signalled = os.environ.get("LT_SLAB_SIGNALLED") == "1"
         self._signalled = bool(signalled)
+        # ``direct`` (RCCL / gloo transport, periodic flows): a double step is TWO launches on the compute stream
+        # -- the edge launch, which reads the planes beyond the cuts straight from the receive buffers and writes
+        # the outgoing messages itself (``lt_stream_collide_twice_edges_direct``), then the sweep over the planes in
+        # between, which never reads a ghost plane -- and one exchange on the communication stream that starts
+        # when the edge launch has finished: no pack launches, no unpack launches, no launches that compete for
+        # the compute units.  None reads LT_SLAB_DIRECT (default on where the engine has the launch).
+        if direct is None:
+            direct = os.environ.get("LT_SLAB_DIRECT", "1") == "1" and not self._signalled
+        self._direct = bool(direct)
+        self._ghost_src = None        # (message from below, message from above) while the ghost planes of the
+        self._parity = 0              # current populations are still in the receive buffers (direct schedule)
         if fused_remote_pack is None:
             self._fused_remote = os.environ.get("LT_SLAB_FUSED_REMOTE_PACK") == "1"
             self.ONE_STREAM_WINDOWS = os.environ.get("LT_SLAB_ONE_STREAM") == "1"
@@ -583,6 +611,7 @@ class TwoStepSlabSimulation(SlabSimulation):
         # 0.367 ms per step with peer windows -- no reason to delay the exchange.
         self.edge_planes = max(2, int(os.environ.get("LT_SLAB_EDGE_PLANES", "2")))
         super().__init__(flow, collision, slab, **kwargs)
+        self._send2 = None
         # every rank must take the same path: agree on whether all engines have a two-step launch
         why = self.engine.two_step_admitted() if hasattr(self.engine, "two_step_admitted") else None
         refused = torch.tensor([0 if why is None else 1], dtype=torch.int32)
@@ -613,12 +642,76 @@ class TwoStepSlabSimulation(SlabSimulation):
         e = np.array(stencil.e)
         return int((e[:, 2] == 0).sum()) + (3 if self._masked else 2) * len(self.up)
 
+    def _direct_ok(self) -> bool:
+        return (self._direct and self._window is None and not self._masked
+                and hasattr(self.engine, "stream_collide_twice_edges_direct")
+                and self.hi - self.lo >= 2 * self.edge_planes)
+
+    def _field_ghosts(self, buf):
+        """the ghost planes of ``buf`` are about to be read by a launch that takes them from the field: scatter
+        the messages the direct schedule left in the receive buffers"""
+        if self._ghost_src is not None:
+            from_below, from_above = self._ghost_src
+            self._ghost_src = None
+            self.engine.unpack_two_step(buf, +1, from_above)
+            self.engine.unpack_two_step(buf, -1, from_below)
+
+    def _present(self):
+        if self._pending is not None:
+            self._field_ghosts(self._pending[0])
+        super()._present()
+
+    def _transfer(self, send_down, send_up):
+        """the halo messages of one double step travel (no packing, no unpacking); returns (message from below,
+        message from above) once they have arrived -- in stream order"""
+        s = self.slab
+        if s.world_size == 1 and not self._force_p2p:
+            return send_up, send_down                 # my own messages: what left upwards arrives from below
+        host = self._host_transport and send_down.is_cuda
+        if host:
+            torch.cuda.current_stream().synchronize()
+        ops = [dist.P2POp(dist.isend, send_down, s.prev, self.group, tag=1),
+               dist.P2POp(dist.irecv, self._recv_down, s.next, self.group, tag=1),
+               dist.P2POp(dist.isend, send_up, s.next, self.group, tag=2),
+               dist.P2POp(dist.irecv, self._recv_up, s.prev, self.group, tag=2)]
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        if host:
+            torch.cuda.current_stream().synchronize()
+        return self._recv_up, self._recv_down
+
+    def _double_step_direct(self, cur, nxt, tau):
+        eng, lo, hi, edge = self.engine, self.lo, self.hi, self.edge_planes
+        if self._send2 is None:
+            # the messages of consecutive double steps alternate between two pairs of buffers: without a transport
+            # (one rank) the launch that reads the last messages writes the next ones
+            self._send2 = (torch.empty_like(self._send_down), torch.empty_like(self._send_up))
+        send_down, send_up = (self._send_down, self._send_up) if self._parity == 0 else self._send2
+        self._parity ^= 1
+        below, above = self._ghost_src if self._ghost_src is not None else (None, None)
+        eng.stream_collide_twice_edges_direct(cur, nxt, tau, edge, below, above, send_down, send_up)
+        if self.overlap:
+            compute = torch.cuda.current_stream()
+            edges_done = torch.cuda.Event()
+            edges_done.record(compute)
+            if hi - lo > 2 * edge:
+                eng.stream_collide_twice_planes(cur, nxt, tau, lo + edge, hi - edge)
+            self._comm.wait_event(edges_done)
+            with torch.cuda.stream(self._comm):
+                self._ghost_src = self._transfer(send_down, send_up)
+            compute.wait_stream(self._comm)
+        else:
+            self._ghost_src = self._transfer(send_down, send_up)
+            if hi - lo > 2 * edge:
+                eng.stream_collide_twice_planes(cur, nxt, tau, lo + edge, hi - edge)
+
     # ---- halo exchange -------------------------------------------------------------------------
     def _exchange(self, buf: torch.Tensor, packed: bool = False):
         """Fill the four ghost planes of ``buf`` (post-collision populations).  My message for the
         lower neighbour comes from my two lowest interior planes and lands in its upper ghost
         planes, and vice versa."""
         eng, s = self.engine, self.slab
+        self._ghost_src = None                        # this exchange ends in the ghost planes of ``buf``
         if self._window is not None:
             if not packed:
                 to_prev, to_next = self._window.targets()
@@ -695,6 +788,8 @@ class TwoStepSlabSimulation(SlabSimulation):
     def _double_step(self, cur, nxt, tau):
         eng, lo, hi = self.engine, self.lo, self.hi
         edge = self.edge_planes
+        if self._direct_ok():
+            return self._double_step_direct(cur, nxt, tau)
         if self._signalled_ok():
             # one launch; the communication stream waits for the edge workgroups' count, not for the launch
             eng.stream_collide_twice_slab(cur, nxt, tau)
@@ -734,6 +829,7 @@ class TwoStepSlabSimulation(SlabSimulation):
             cur, nxt = nxt, cur
             fused -= 2
         if fused == 1:
+            self._field_ghosts(cur)
             eng.stream_collide_planes(cur, nxt, tau, lo, hi)
             cur, nxt = nxt, cur
             self._exchange(cur)()

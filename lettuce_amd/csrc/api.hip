@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 
 #include "dispatch.hpp"
@@ -104,7 +105,20 @@ struct lt_plan {
   unsigned long long signal_target = 0;
   unsigned *signal_timed_out = nullptr;
   unsigned long long *signal_now = nullptr;   // where step() finds the counter for the launch being issued (or null)
+  const void *ghost_lo_now = nullptr, *ghost_hi_now = nullptr;   // received halo messages the edge launch being issued reads
   int defer_stream = 0;      // lt_run / lt_continue stop before their last (streaming) pass (lt_plan_set_deferred_stream)
+  // distance between consecutive populations of the caller's buffers, in elements (lt_plan_set_population_stride);
+  // 0 = dense (N).  stride_in_now / stride_out_now: what step() uses for the launch being issued when the two
+  // differ from it (the resident entry points move between the caller's dense buffers and the padded ones)
+  long long pop_stride = 0;
+  long long stride_in_now = -1, stride_out_now = -1;
+  // engine-owned padded population buffers (lt_resident_*): res[res_cur] holds the post-collision populations
+  int resident = -1;         // -1 = automatic, 0 = off, 1 = on (lt_plan_set_resident)
+  long long res_pad = -1;    // elements between the end of one population and the start of the next; -1 = automatic
+  long long res_stride = 0;  // stride of the allocated buffers
+  void *res[2] = {nullptr, nullptr};
+  int res_cur = 0;
+  int res_valid = 0;
   char kernel_name[192];
   // launch-bound grids: a captured hipGraph of kGraphChunk fused steps (ping-pong returns to the
   // starting buffer), replayed on a plan-owned stream that is forked from / joined to the caller's
@@ -116,6 +130,9 @@ struct lt_plan {
 };
 
 namespace {
+
+// elements between consecutive populations of the caller's buffers
+long long pop_stride_of(const lt_plan *p) { return p->pop_stride > 0 ? p->pop_stride : p->N; }
 
 int mem_axis_of(const lt_plan *p, int logical_axis) {
   if (p->unit.d == 1) return 0;
@@ -222,14 +239,14 @@ int pack(lt_plan *p, bool do_pack, void *f, long long plane, int dir, void *buf,
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (p->desc.dtype == LT_F32) {
     if (do_pack) hipLaunchKernelGGL((lt::plane_pack_kernel<float, true>), dim3(grid), dim3(lt::kThreads), 0, s,
-                                    (float *)f, (float *)buf, p->N, off, plane_nodes, ql);
+                                    (float *)f, (float *)buf, pop_stride_of(p), off, plane_nodes, ql);
     else hipLaunchKernelGGL((lt::plane_pack_kernel<float, false>), dim3(grid), dim3(lt::kThreads), 0, s,
-                            (float *)f, (float *)buf, p->N, off, plane_nodes, ql);
+                            (float *)f, (float *)buf, pop_stride_of(p), off, plane_nodes, ql);
   } else {
     if (do_pack) hipLaunchKernelGGL((lt::plane_pack_kernel<double, true>), dim3(grid), dim3(lt::kThreads), 0, s,
-                                    (double *)f, (double *)buf, p->N, off, plane_nodes, ql);
+                                    (double *)f, (double *)buf, pop_stride_of(p), off, plane_nodes, ql);
     else hipLaunchKernelGGL((lt::plane_pack_kernel<double, false>), dim3(grid), dim3(lt::kThreads), 0, s,
-                            (double *)f, (double *)buf, p->N, off, plane_nodes, ql);
+                            (double *)f, (double *)buf, pop_stride_of(p), off, plane_nodes, ql);
   }
   LT_HIP(hipGetLastError());
   return LT_OK;
@@ -260,20 +277,64 @@ int resolve_lds(const lt_plan *p, long long workgroups) {
   return per_wg > 65536 ? 65536 : per_wg;
 }
 
+// ---- engine-owned padded population buffers (lt_resident_*) ----
+// Distance added between consecutive populations of the engine's own buffers.  The q read streams and q write
+// streams of a node advance in lockstep; with the populations a power of two apart (256^3 fp32: exactly 64 MiB)
+// they meet in the same memory channels.  Measured on MI355X (tools/pad_sweep_probe.py).
+long long default_pad(const lt_plan *p) {
+  return 2368 / p->esize * 4;       // bytes: 9472 = 37 * 256 -- an odd number of 256-byte channel units
+}
+long long resident_stride(const lt_plan *p) {
+  const long long pad = p->res_pad >= 0 ? p->res_pad : default_pad(p);
+  const long long unit = 256 / p->esize;                      // keep every population 256-byte aligned
+  return (p->N + pad + unit - 1) / unit * unit;
+}
+bool resident_wanted(const lt_plan *p) {
+  if (p->desc.ghost_planes || p->unit.d < 2) return false;
+  if (p->resident >= 0) return p->resident != 0;
+  // automatic: the streaming regime (populations beyond the caches), where the launches are bound by HBM
+  return 2ll * p->unit.q * p->N * p->esize > (128ll << 20);
+}
+int resident_alloc(lt_plan *p) {
+  const long long stride = resident_stride(p);
+  if (p->res[0] && p->res_stride == stride) return LT_OK;
+  for (void *&r : p->res) { if (r) (void)hipFree(r); r = nullptr; }
+  p->res_valid = 0;
+  const size_t bytes = (size_t)stride * p->unit.q * p->esize;
+  for (void *&r : p->res)
+    if (hipMalloc(&r, bytes) != hipSuccess) {
+      for (void *&x : p->res) { if (x) (void)hipFree(x); x = nullptr; }
+      return fail(LT_ERR_ALLOC, "hipMalloc of the resident population buffers (2 x %zu bytes) failed", bytes);
+    }
+  p->res_stride = stride;
+  return LT_OK;
+}
+
 // the two-step tile (the rule of unit.inc): rows of 256 bytes, 8 or 4 of them; rows = 0: no kernel
 struct TwoStepTile { int width, rows; };
-TwoStepTile two_step_tile(const lt_plan *p) {
-  if (p->unit.d == 2) {
+TwoStepTile two_step_tile_of(int d, int q, int esize, int n0) {
+  if (d == 2) {
     // 2-D (twostep2d.hpp): strips of `width` columns, the widest that divides the contiguous extent; one "row"
     for (int w = 512; w >= 64; w /= 2)
-      if (p->n0 % w == 0) return {w, 1};
+      if (n0 % w == 0) return {w, 1};
     return {0, 0};
   }
-  const long long per_node = (long long)p->esize * 3 * p->unit.q;
-  const int width = 256 / p->esize;
+  const long long per_node = (long long)esize * 3 * q;
+  const int width = 256 / esize;
   const int rows = per_node * (width + 2) * 10 <= 160 * 1024
-                       ? 8 : (p->esize == 4 && per_node * (width + 2) * 6 <= 160 * 1024 ? 4 : 0);
+                       ? 8 : (esize == 4 && per_node * (width + 2) * 6 <= 160 * 1024 ? 4 : 0);
   return {width, rows};
+}
+TwoStepTile two_step_tile(const lt_plan *p) { return two_step_tile_of(p->unit.d, p->unit.q, p->esize, p->n0); }
+
+// The 3-D two-step kernels address with 32-bit byte offsets: lbm2_kernel within a plane, lbm2m_kernel (buffer
+// instructions) within the whole field -- the rule of unit.inc's launch_twice / launch_twice_masked, which return
+// kNoKernel beyond it.  Asked BEFORE a plan is put on the two-step path, so that lt_run falls back to the one-step
+// kernel instead of failing at the first launch (Obstacle D3Q19 fp32 at 384^3 is 4.0 GiB).
+bool two_step_addressable(int d, int q, int esize, long long n0, long long n1, long long n2, bool masked) {
+  if (d != 3) return true;
+  if (masked) return (long long)q * n0 * n1 * n2 * esize < (1ll << 32);
+  return n0 * n1 * esize < (1ll << 32);
 }
 
 // planes per workgroup of the two-step kernel.  One workgroup occupies a CU (150 KB of LDS), so the
@@ -332,14 +393,14 @@ int halo2(lt_plan *p, bool do_pack, void *f, int side, void *buf, void *stream) 
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (p->desc.dtype == LT_F32) {
     if (do_pack) hipLaunchKernelGGL((lt::halo2_kernel<float, true>), dim3(grid), dim3(lt::kThreads), 0, s, (float *)f,
-                                    (float *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross, away);
+                                    (float *)buf, pop_stride_of(p), near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross, away);
     else hipLaunchKernelGGL((lt::halo2_kernel<float, false>), dim3(grid), dim3(lt::kThreads), 0, s, (float *)f,
-                            (float *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross, away);
+                            (float *)buf, pop_stride_of(p), near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross, away);
   } else {
     if (do_pack) hipLaunchKernelGGL((lt::halo2_kernel<double, true>), dim3(grid), dim3(lt::kThreads), 0, s, (double *)f,
-                                    (double *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross, away);
+                                    (double *)buf, pop_stride_of(p), near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross, away);
     else hipLaunchKernelGGL((lt::halo2_kernel<double, false>), dim3(grid), dim3(lt::kThreads), 0, s, (double *)f,
-                            (double *)buf, p->N, near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross, away);
+                            (double *)buf, pop_stride_of(p), near * plane_nodes, far * plane_nodes, plane_nodes, in_plane, cross, away);
   }
   LT_HIP(hipGetLastError());
   return LT_OK;
@@ -427,7 +488,8 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
       if (b.kind == LT_BOUNDARY_ABB_OUTLET && !(b.flags & LT_BOUNDARY_ABSENT) && mem_axis_of(p, b.axis) == 0)
         a.abb0_slot = i + 1;
     }
-  const bool aligned = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  const bool aligned = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                       (p->pop_stride * p->esize) % 16 == 0 && p->stride_in_now < 0 && p->stride_out_now < 0;
   const bool hot = mode == lt::kFused && !a.masked && a.coll == LT_COLLISION_BGK;
   a.wide = (p->want_wide && hot && p->wide_ok && aligned) ? 1 : 0;
   a.shift = a.wide ? p->shift : 0;
@@ -438,8 +500,12 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   if (mode == lt::kFusedTwice) a.shift = p->shift;      // tile-shape A/B variant
   if (mode == lt::kFusedMany) a.seg_len = p->many_now;
   a.stream = static_cast<hipStream_t>(stream);
+  a.stride_in = p->stride_in_now >= 0 ? p->stride_in_now : p->pop_stride;
+  a.stride_out = p->stride_out_now >= 0 ? p->stride_out_now : p->pop_stride;
   a.pack_lo = pack_lo; a.pack_hi = pack_hi;
   a.signal = p->signal_now;
+  a.ghost_lo = p->ghost_lo_now; a.ghost_hi = p->ghost_hi_now;
+  a.interior_begin = p->interior_begin; a.interior_end = p->interior_end;
   a.pack_lo_plane = (int)pb; a.pack_hi_plane = (int)(pb + stride * (a.planes - 1));
   if (mode == lt::kFusedTwice) {
     a.p_begin2 = (int)p->second_begin;
@@ -521,6 +587,15 @@ bool two_step_possible(lt_plan *p, const char **why) {
     *why = "the grid does not tile (contiguous extent % 64 (fp32) / 32 (fp64), middle extent % 8 or 4)";
     return false;
   }
+  // with masks the whole (padded) field is addressed with 32-bit offsets
+  const long long widest = std::max(pop_stride_of(p), resident_wanted(p) ? resident_stride(p) : 0ll);
+  if (!two_step_addressable(p->unit.d, p->unit.q, p->esize, p->n0, p->n1, p->n2, p->masked != 0) ||
+      (p->masked && p->unit.d == 3 && (long long)p->unit.q * widest * p->esize >= (1ll << 32))) {
+    *why = p->masked ? "with boundaries the two-step kernel addresses the field with 32-bit offsets: q * nodes * sizeof(scalar) "
+                       "must stay below 4 GiB"
+                     : "a plane of the grid exceeds the two-step kernel's 32-bit in-plane offsets";
+    return false;
+  }
   if (p->masked && (!masked_two_step_ok(p) || (p->desc.ghost_planes && p->n_abb > 0 && masked_two_step_axis(p) != 0))) {
     *why = "boundaries: at most one anti-bounce-back outlet, at the last plane of the slowest memory axis (periodic "
            "plans only) or at an end of the contiguous axis opposite a face of equilibrium nodes; no-streaming bits "
@@ -579,30 +654,17 @@ bool many_step_wanted(lt_plan *p) {
   return p->N <= 256ll * 256ll;
 }
 
-int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, void *stream,
-        int32_t *result_in_b) {
-  if (!p) return fail(LT_ERR_INVALID, "null plan");
-  if (n < 1) return fail(LT_ERR_INVALID, "n_steps = %lld", n);
-  if (!result_in_b) return fail(LT_ERR_INVALID, "null result_in_b");
-  if (p->desc.ghost_planes)
-    return fail(LT_ERR_UNSUPPORTED, "lt_run/lt_continue need a periodic plan (no ghost planes); "
-                                    "drive slabs with the *_planes entry points");
-  void *cur = a, *other = b;
+// `fused` stream-collide steps starting from the post-collision populations in *cur, ping-ponging with *other (both
+// pointers are updated: on return *cur holds the result): pairs of steps through the two-step kernel where it
+// applies, the rest one by one; several steps per launch on small 2-D grids.  The optional events bracket the
+// dominant kind of launch only.
+int fused_section(lt_plan *p, void *&cur, void *&other, double tau, long long fused, void *stream) {
   int rc;
-  long long fused = n;
-  if (!from_fstar) {
-    rc = step(p, lt::kCollideOnly, cur, other, tau, 0, p->n2, stream);
-    if (rc) return rc;
-    void *t = cur; cur = other; other = t;
-    fused = n - 1;
-  }
-  if (graph_wanted(p, fused)) {
+  if (graph_wanted(p, fused) && p->stride_in_now < 0) {
     const long long done = run_graph(p, cur, other, tau, fused, stream);
     if (done < 0) return (int)-done;
     fused -= done;                       // an even number of steps: still in `cur`
   }
-  // fused section: pairs of steps through the two-step kernel where it applies, the rest one by
-  // one.  The optional events bracket the dominant kind of launch only.
   hipStream_t hs = static_cast<hipStream_t>(stream);
   p->last_many = 0;
   if (many_step_wanted(p) && fused >= 2) {
@@ -618,7 +680,8 @@ int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, 
     }
     if (p->ev_stop) (void)hipEventRecord(p->ev_stop, hs);
     p->last_twice = p->last_single = 0;
-  } else {
+    return LT_OK;
+  }
   const long long twice = two_step_wanted(p) ? fused / 2 : 0;
   const long long single = fused - 2 * twice;
   p->last_twice = twice; p->last_single = single;
@@ -636,7 +699,28 @@ int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, 
     void *t = cur; cur = other; other = t;
   }
   if (p->ev_stop && twice == 0) (void)hipEventRecord(p->ev_stop, hs);
+  return LT_OK;
+}
+
+int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, void *stream,
+        int32_t *result_in_b) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (n < 1) return fail(LT_ERR_INVALID, "n_steps = %lld", n);
+  if (!result_in_b) return fail(LT_ERR_INVALID, "null result_in_b");
+  if (p->desc.ghost_planes)
+    return fail(LT_ERR_UNSUPPORTED, "lt_run/lt_continue need a periodic plan (no ghost planes); "
+                                    "drive slabs with the *_planes entry points");
+  void *cur = a, *other = b;
+  int rc;
+  long long fused = n;
+  if (!from_fstar) {
+    rc = step(p, lt::kCollideOnly, cur, other, tau, 0, p->n2, stream);
+    if (rc) return rc;
+    void *t = cur; cur = other; other = t;
+    fused = n - 1;
   }
+  rc = fused_section(p, cur, other, tau, fused, stream);
+  if (rc) return rc;
   if (p->defer_stream) {               // the caller streams when somebody wants to see the populations
     *result_in_b = (cur == b) ? 1 : 0;
     return LT_OK;
@@ -656,6 +740,10 @@ int aux(lt_plan *p, int what, const void *f, void *rho, void *u, double *out, vo
   a.what = what; a.layout = p->desc.layout;
   a.f = f; a.rho = rho; a.u = u;
   a.N = p->N;
+  a.stride = pop_stride_of(p);
+  if (a.stride != a.N && what != 0 && what != 2 && what != 3 && what != 4)
+    return fail(LT_ERR_UNSUPPORTED, "auxiliary kernel %d reads dense population buffers only (the plan has a "
+                                    "population stride of %lld)", what, a.stride);
   const long long plane = (long long)p->n0 * p->n1;
   a.first = plane * p->interior_begin;
   a.count = plane * (p->interior_end - p->interior_begin);
@@ -755,6 +843,7 @@ int lt_plan_destroy(lt_plan *p) {
   if (p->signal) (void)hipFree(p->signal);
   if (p->signal_timed_out) (void)hipFree(p->signal_timed_out);
   if (p->partial) (void)hipFree(p->partial);
+  for (void *r : p->res) if (r) (void)hipFree(r);
   if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
   if (p->gev_in) (void)hipEventDestroy(p->gev_in);
   if (p->gev_out) (void)hipEventDestroy(p->gev_out);
@@ -989,6 +1078,83 @@ int lt_plan_set_deferred_stream(lt_plan *p, int32_t on) {
   return LT_OK;
 }
 
+int lt_plan_set_population_stride(lt_plan *p, int64_t stride) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (stride != 0 && (stride < p->N || (stride * p->esize) % 256 != 0))
+    return fail(LT_ERR_INVALID, "population stride %lld: 0 (dense) or >= %lld nodes and a multiple of 256 bytes",
+                (long long)stride, p->N);
+  p->pop_stride = stride == p->N ? 0 : stride;
+  return LT_OK;
+}
+int lt_plan_population_stride(lt_plan *p, int64_t *stride) {
+  if (!p || !stride) return fail(LT_ERR_INVALID, "null argument");
+  *stride = pop_stride_of(p);
+  return LT_OK;
+}
+
+// ---- engine-owned padded population buffers ----------------------------------------------------------------
+int lt_plan_set_resident(lt_plan *p, int32_t mode, int64_t pad_elements) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (mode < -1 || mode > 1) return fail(LT_ERR_INVALID, "resident mode %d", mode);
+  if (pad_elements < -1) return fail(LT_ERR_INVALID, "pad %lld", (long long)pad_elements);
+  if (mode == 1 && (p->desc.ghost_planes || p->unit.d < 2))
+    return fail(LT_ERR_UNSUPPORTED, "resident populations: periodic 2-D / 3-D plans (slab ranks own their buffers: "
+                                    "lt_plan_set_population_stride)");
+  p->resident = mode;
+  if (pad_elements != p->res_pad) p->res_valid = 0;
+  p->res_pad = pad_elements;
+  return LT_OK;
+}
+int lt_resident_enabled(lt_plan *p, int32_t *enabled, int64_t *stride) {
+  if (!p || !enabled) return fail(LT_ERR_INVALID, "null argument");
+  *enabled = resident_wanted(p) ? 1 : 0;
+  if (stride) *stride = resident_stride(p);
+  return LT_OK;
+}
+int lt_resident_load(lt_plan *p, const void *f, double tau, void *stream) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (p->desc.ghost_planes) return fail(LT_ERR_UNSUPPORTED, "resident populations need a periodic plan");
+  int rc = resident_alloc(p);
+  if (rc) return rc;
+  p->res_valid = 0;
+  p->stride_in_now = pop_stride_of(p); p->stride_out_now = p->res_stride;
+  rc = step(p, lt::kCollideOnly, f, p->res[0], tau, 0, p->n2, stream);
+  p->stride_in_now = p->stride_out_now = -1;
+  if (rc) return rc;
+  p->res_cur = 0;
+  p->res_valid = 1;
+  return LT_OK;
+}
+int lt_resident_advance(lt_plan *p, double tau, int64_t n, void *stream) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (n < 0) return fail(LT_ERR_INVALID, "n_steps = %lld", (long long)n);
+  if (!p->res_valid) return fail(LT_ERR_INVALID, "no resident populations: call lt_resident_load first");
+  p->last_single = p->last_twice = p->last_many = 0;
+  if (n == 0) return LT_OK;
+  void *cur = p->res[p->res_cur], *other = p->res[1 - p->res_cur];
+  p->stride_in_now = p->stride_out_now = p->res_stride;
+  const int rc = fused_section(p, cur, other, tau, n, stream);
+  p->stride_in_now = p->stride_out_now = -1;
+  if (rc) { p->res_valid = 0; return rc; }
+  p->res_cur = cur == p->res[0] ? 0 : 1;
+  return LT_OK;
+}
+int lt_resident_store(lt_plan *p, void *out, void *stream) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (!p->res_valid) return fail(LT_ERR_INVALID, "no resident populations: call lt_resident_load first");
+  p->stride_in_now = p->res_stride; p->stride_out_now = pop_stride_of(p);
+  const int rc = step(p, lt::kStreamOnly, p->res[p->res_cur], out, 1.0, 0, p->n2, stream);
+  p->stride_in_now = p->stride_out_now = -1;
+  return rc;
+}
+int lt_resident_free(lt_plan *p) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  for (void *&r : p->res) { if (r) (void)hipFree(r); r = nullptr; }
+  p->res_valid = 0;
+  p->res_stride = 0;
+  return LT_OK;
+}
+
 int lt_plan_set_graph_mode(lt_plan *p, int32_t mode) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (mode < -1 || mode > 1) return fail(LT_ERR_INVALID, "graph mode %d", mode);
@@ -1034,6 +1200,19 @@ int lt_stream_collide_twice_edges(lt_plan *p, const void *f, void *out, double t
   const int rc = step(p, lt::kFusedTwice, f, out, tau, lo, lo + edge_planes, stream, 1, pack_lower, pack_upper);
   p->seg_len = saved;
   p->second_begin = p->second_end = 0;
+  return rc;
+}
+int lt_stream_collide_twice_edges_direct(lt_plan *p, const void *f, void *out, double tau, int32_t edge_planes,
+                                         const void *recv_lower, const void *recv_upper, void *pack_lower,
+                                         void *pack_upper, void *stream) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (!pack_lower || !pack_upper || (recv_lower == nullptr) != (recv_upper == nullptr))
+    return fail(LT_ERR_INVALID, "the direct edge launch needs both send buffers, and both received messages or "
+                                "neither (then the ghost planes of f_dev are read)");
+  if (p->masked) return fail(LT_ERR_UNSUPPORTED, "the direct edge launch exists for plans without masks");
+  p->ghost_lo_now = recv_lower; p->ghost_hi_now = recv_upper;
+  const int rc = lt_stream_collide_twice_edges(p, f, out, tau, edge_planes, pack_lower, pack_upper, stream);
+  p->ghost_lo_now = p->ghost_hi_now = nullptr;
   return rc;
 }
 // The whole slab in one launch that feeds the exchange while it runs: see include/lettuce_hip.h
@@ -1088,6 +1267,9 @@ int lt_slab_wait_timed_out(lt_plan *p, int32_t *timed_out, void *stream) {
     hipStream_t hs = static_cast<hipStream_t>(stream);
     LT_HIP(hipMemcpyAsync(&flag, p->signal_timed_out, sizeof flag, hipMemcpyDeviceToHost, hs));
     LT_HIP(hipStreamSynchronize(hs));
+    // reported once: the next batch starts with a clean word (the counter itself stays consistent -- every edge
+    // workgroup of the launch that was waited for still adds its 1)
+    if (flag) LT_HIP(hipMemsetAsync(p->signal_timed_out, 0, sizeof(unsigned), hs));
   }
   *timed_out = (int32_t)flag;
   return LT_OK;
@@ -1096,6 +1278,25 @@ int lt_plan_two_step_admitted(lt_plan *p) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   const char *why = "";
   if (!two_step_possible(p, &why)) return fail(LT_ERR_UNSUPPORTED, "two steps per launch: %s", why);
+  return LT_OK;
+}
+int lt_two_step_limits(const lt_plan_desc *d, int32_t masked, int32_t *tile_width, int32_t *tile_rows,
+                       int32_t *addressable) {
+  if (!d) return fail(LT_ERR_INVALID, "null descriptor");
+  if (d->stencil < 0 || d->stencil > 4) return fail(LT_ERR_UNSUPPORTED, "stencil %d", d->stencil);
+  if (d->dtype < 0 || d->dtype > 1) return fail(LT_ERR_UNSUPPORTED, "dtype %d (fp32/fp64 only)", d->dtype);
+  const Unit &unit = kUnits[d->stencil][d->dtype];
+  if (d->dims != unit.d) return fail(LT_ERR_INVALID, "stencil is %d-dimensional, dims = %d", unit.d, d->dims);
+  const int esize = d->dtype == LT_F32 ? 4 : 8;
+  long long e0, e1, e2;
+  if (unit.d == 1) { e0 = d->shape[0]; e1 = 1; e2 = 1; }
+  else if (unit.d == 2) { e0 = d->shape[1]; e1 = d->shape[0]; e2 = 1; }
+  else if (d->layout == LT_LAYOUT_REFERENCE) { e0 = d->shape[2]; e1 = d->shape[1]; e2 = d->shape[0]; }
+  else { e0 = d->shape[0]; e1 = d->shape[1]; e2 = d->shape[2] + 2 * d->ghost_planes; }
+  const TwoStepTile tile = unit.d >= 2 ? two_step_tile_of(unit.d, unit.q, esize, (int)e0) : TwoStepTile{0, 0};
+  if (tile_width) *tile_width = tile.width;
+  if (tile_rows) *tile_rows = tile.rows;
+  if (addressable) *addressable = two_step_addressable(unit.d, unit.q, esize, e0, e1, e2, masked != 0) ? 1 : 0;
   return LT_OK;
 }
 int lt_slab_two_step_message_blocks(lt_plan *p, int32_t *blocks) {

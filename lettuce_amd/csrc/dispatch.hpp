@@ -12,6 +12,7 @@ struct StepArgs {
   const void *in;
   void *out;
   int n0, n1, n2;        // memory extents (n2 incl. ghost planes)
+  long long stride_in, stride_out;   // elements between consecutive populations of in / out; 0 = dense (n0*n1*n2)
   int p_begin, planes;   // a2 planes of this launch: p_begin + i * p_stride, i < planes
   int p_stride;
   int p_begin2, planes2;  // kFusedTwice: optional second range of output planes
@@ -32,6 +33,8 @@ struct StepArgs {
   void *pack_lo, *pack_hi;         // fused halo packing (slab boundary launch) or null
   int pack_lo_plane, pack_hi_plane;
   unsigned long long *signal;      // kFusedTwice with both message buffers: edge workgroups first, each adds 1 here (or null)
+  const void *ghost_lo, *ghost_hi; // kFusedTwice edge launch: received halo messages to read the planes beyond the cuts from (or null)
+  int interior_begin, interior_end;   // first interior plane, one past the last
   hipStream_t stream;
 };
 
@@ -43,6 +46,7 @@ struct AuxArgs {
   void *rho;             // what 0: out, what 1: in
   void *u;               // what 0: out, what 1: in
   long long N;           // nodes per population (incl. ghost planes)
+  long long stride;      // elements between consecutive populations of f (what 0, 2, 3, 4; dense = N elsewhere)
   long long first, count;  // node range reduced (what 2, 3)
   double *partial;       // plan scratch, >= reduce_blocks doubles
   int reduce_blocks;

@@ -57,7 +57,10 @@ struct KParams {
   int p_begin2, p_end2;      // two-step kernel: optional second range of output planes (slab edges)
   int p_stride;              // distance between consecutive planes of this launch (normally 1)
   int wrap2;                 // periodic wrap along a2 (0 with ghost planes)
-  long long N;               // n0*n1*n2 = stride between populations
+  long long N;               // n0*n1*n2: nodes per population (and the stride of a boundary's per-node field)
+  long long Ni, No;          // distance between consecutive populations of `in` / of `out`, in elements (>= N:
+                             // engine-owned buffers are padded so that the q streams of a node do not meet in the
+                             // same memory channels, DESIGN.md section 4 "population stride")
   unsigned nvec_total;       // threads doing work: nv0 * n1 * planes
   T tau_inv;                 // BGK: 1/tau
   T beta, inv_beta;          // KBC: 1/(2 tau), 1/beta
@@ -80,6 +83,12 @@ struct KParams {
   // two planes next to the cut are in memory (wait_counter_kernel on the communication stream polls it)
   unsigned long long *signal;
   int edge_first;
+  // two-step slab EDGE launch that takes the neighbours' planes straight from the receive buffers (MODE 1 of
+  // lbm2_kernel): ghost_lo / ghost_hi = the halo message that arrived from the rank below / above (layout of
+  // halo2_kernel), read wherever the pull reaches below plane `lo` / beyond plane `hi - 1`; null = the ghost planes
+  // of the field hold them (they were unpacked)
+  const T *ghost_lo, *ghost_hi;
+  int lo, hi;                // first interior plane, one past the last interior plane
 };
 
 // ---- constants the reference builds from cs = 1/np.sqrt(3.0) (lettuce/_stencil.py:17) ----
@@ -177,7 +186,7 @@ __device__ __forceinline__ void gather(const KParams<T> &p, const Coord &c, T (&
   const unsigned own = (unsigned)(c.c2 * n1 + c.c1) * (unsigned)n0 + (unsigned)c.c0;
   static_for<S::Q>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
-    const T *__restrict__ src = p.in + (long long)q * p.N;
+    const T *__restrict__ src = p.in + (long long)q * p.Ni;
     if constexpr (!STREAM) {
       vload<T, VEC, NTL>(src + own, f[q]);
     } else {
@@ -261,7 +270,7 @@ __device__ __forceinline__ void keep_unstreamed(const KParams<T> &p, unsigned ow
   static_for<S::Q>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
     if constexpr (q > 0) {   // population 0 never moves (_simulation.py:165)
-      if (bits & (1u << q)) f[q][k] = p.in[(long long)q * p.N + own + k];
+      if (bits & (1u << q)) f[q][k] = p.in[(long long)q * p.Ni + own + k];
     }
   });
 }
@@ -828,7 +837,7 @@ __device__ __forceinline__ void lbm_body(const KParams<T> &p) {
 
   static_for<S::Q>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
-    vstore<T, VEC, (TUNE & 2) != 0>(p.out + (long long)q * p.N + own, f[q]);
+    vstore<T, VEC, (TUNE & 2) != 0>(p.out + (long long)q * p.No + own, f[q]);
   });
   if constexpr (PACK) {
     // halo packing fused into the boundary-plane launch of the slab driver (saves two pack
@@ -905,10 +914,15 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename T, class S, int LAYOUT, int COLL, int T0_, int T1, int NPT = 1, bool PACK = false,
+// MODE (slab layout): 0 = plain sweep; 1 = edge launch: every workgroup also writes the halo messages, and the
+// planes beyond the cuts are read from the receive buffers when p.ghost_lo / p.ghost_hi are given; 2 = launch
+// over the whole slab whose edge workgroups start first and count themselves done (p.signal).
+template <typename T, class S, int LAYOUT, int COLL, int T0_, int T1, int NPT = 1, int MODE = 0,
           int NPB = NPT>
 __global__ void __launch_bounds__(((TwoStep<T, S, T0_, T1>::NI / NPT + 63) / 64 * 64))
 lbm2_kernel(const KParams<T> p, const int seg_len) {
+  constexpr bool PACK = MODE == 1;
+  static_assert(MODE == 0 || LAYOUT == 1, "edge / signalling launches exist in the slab layout");
   // NPT intermediate nodes and NPB output nodes per thread (1 or 2): thread t owns intermediate
   // nodes t + k NA, k < NPT, and output nodes t + k NB, k < NPB
   using B = TwoStep<T, S, T0_, T1>;
@@ -930,7 +944,7 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   // share are then fetched into one L2 once instead of into two L2s.
   int b = blockIdx.x;
   const int segs_a = (p.p_end - p.p_begin + seg_len - 1) / seg_len;
-  if (LAYOUT == 1 && p.edge_first) {
+  if (MODE == 2) {
     // edges first (the hardware starts workgroups in index order): upper edge = the one segment of the second
     // range, then the first segment of the first range, then the rest with the XCD-aware numbering
     // (XCD-aware within each layer of tiles)
@@ -1016,7 +1030,22 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
         constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1), e2 = M::e(q, 2);
         const int z = e2 == 0 ? g2 : (e2 > 0 ? g2m : g2p);
         // 32-bit scalar multiply (a plane's first node index fits: N < 2^31), 64-bit scalar add
-        const T *base = p.in + ((long long)q * p.N + (long long)((unsigned)z * plane_nodes));
+        const T *base = p.in + ((long long)q * p.Ni + (long long)((unsigned)z * plane_nodes));
+        if constexpr (MODE == 1) {
+          // Planes beyond a cut: the neighbour's populations as they arrived (halo2_kernel's message: in-plane
+          // populations of its plane next to the cut | the crossing ones of that plane | the crossing ones of the
+          // plane behind it).  The plane index is uniform, so this is scalar work; the populations moving away
+          // from a cut are never pulled across it.
+          constexpr int rank = crossing_rank<S, LAYOUT, q>();
+          if constexpr (e2 >= 0) {
+            if (p.ghost_lo != nullptr && z < p.lo)
+              base = p.ghost_lo + (size_t)(e2 == 0 ? rank : (z == p.lo - 1 ? NC + rank : NC + NU + rank)) * plane_nodes;
+          }
+          if constexpr (e2 <= 0) {
+            if (p.ghost_hi != nullptr && z >= p.hi)
+              base = p.ghost_hi + (size_t)(e2 == 0 ? rank : (z == p.hi ? NC + rank : NC + ND + rank)) * plane_nodes;
+          }
+        }
         static_for<NPT>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
           pre[q][k] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + voff[k][e1 + 1][e0 + 1]);
@@ -1073,7 +1102,7 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
     if (in_b) {
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        T *base = p.out + ((long long)q * p.N + (long long)((unsigned)k2 * plane_nodes));
+        T *base = p.out + ((long long)q * p.No + (long long)((unsigned)k2 * plane_nodes));
         static_for<NPB>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
           T *at = reinterpret_cast<T *>(reinterpret_cast<char *>(base) + out_off[k]);
@@ -1143,14 +1172,18 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
     // registers, message stores -- and even its presence slows the other copy: a launch over the whole slab
     // with packing first segments took 1.0 instead of 0.6 ms, so that launch does not pack.)
     for (; k < last; ++k) interval(k, std::integral_constant<int, 1>{});
-  } else if constexpr (LAYOUT == 1) {
-    if (p.edge_first && (second || b == 0)) {
+  } else if constexpr (MODE == 2) {
+    if (second || b == 0) {
       // Launch over the whole slab: the planes next to a cut are this workgroup's last two (upper edge) or first
       // two (lower edge).  They are stored at device scope, and once the stores have been performed the
       // workgroup counts itself done.  No release fence: at device scope that is a write-back of the XCD's
       // whole L2 -- 1024 of them made the launch take 0.99 instead of 0.66 ms.
       const int until = second ? last : (s + 2 < last ? s + 2 : last);
       for (; k < until; ++k) interval(k, std::integral_constant<int, 2>{});
+      // every wave waits until ITS edge-plane stores have been acknowledged (they are write-through stores at
+      // device scope, so the acknowledgement means "performed in memory"): a workgroup-scope release alone emits
+      // no vmcnt wait on gfx950, and the counter below must not become visible before the planes are
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(p.signal, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1296,9 +1329,9 @@ lbm_many_kernel(const KParams<T> p, const int K) {
       constexpr int q = decltype(qc)::value;
       constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1);
       const int s0 = e0 == 0 ? g0 : wrap(g0 - e0, p.n0), s1 = e1 == 0 ? g1 : wrap(g1 - e1, p.n1);
-      f[q][0] = p.in[(long long)q * p.N + (long long)s1 * p.n0 + s0];
+      f[q][0] = p.in[(long long)q * p.Ni + (long long)s1 * p.n0 + s0];
       if constexpr (MASKED && q > 0) {
-        if (bits & (1u << q)) f[q][0] = p.in[(long long)q * p.N + own];
+        if (bits & (1u << q)) f[q][0] = p.in[(long long)q * p.Ni + own];
       }
     });
     collide_and_bound(f, [&](T &rn, T (&jn)[3]) {
@@ -1348,7 +1381,7 @@ lbm_many_kernel(const KParams<T> p, const int K) {
   if (in_region && i0 >= halo && i0 < r0 - halo && i1 >= halo && i1 < r1 - halo) {
     static_for<S::Q>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
-      p.out[(long long)q * p.N + own] = f[q][0];
+      p.out[(long long)q * p.No + own] = f[q][0];
     });
   }
 }
@@ -1359,14 +1392,14 @@ template <typename T, class S, int LAYOUT>
 __global__ void __launch_bounds__(kThreads) macroscopic_kernel(const T *__restrict__ f,
                                                                T *__restrict__ rho_out,
                                                                T *__restrict__ u_out,
-                                                               long long N) {
+                                                               long long N, long long stride) {
   using M = MemMap<S, LAYOUT>;
   const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (i >= N) return;
   T g[S::Q][1];
   static_for<S::Q>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
-    g[q][0] = f[(long long)q * N + i];
+    g[q][0] = f[(long long)q * stride + i];
   });
   T rho, j[3];
   moments<T, S, LAYOUT, 1, 0>(g, rho, j);

@@ -73,7 +73,7 @@ lbm2d2_kernel(const KParams<T> p, const int seg_len) {
         constexpr int q = decltype(qc)::value;
         constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1);
         const int z = e1 == 0 ? g1 : (e1 > 0 ? g1m : g1p);
-        pre[q][0] = p.in[(long long)q * p.N + (long long)((unsigned)z * n0 + col[e0 + 1])];
+        pre[q][0] = p.in[(long long)q * p.Ni + (long long)((unsigned)z * n0 + col[e0 + 1])];
       });
     }
   };
@@ -108,7 +108,7 @@ lbm2d2_kernel(const KParams<T> p, const int seg_len) {
       if constexpr (COLL == 1) collide_bgk<T, S, 0, 1, 0>(f, p.tau_inv);
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        __builtin_nontemporal_store(f[q][0], p.out + ((long long)q * p.N + (long long)((unsigned)k * n0 + out_col)));
+        __builtin_nontemporal_store(f[q][0], p.out + ((long long)q * p.No + (long long)((unsigned)k * n0 + out_col)));
       });
     }
   };
@@ -225,7 +225,7 @@ lbm2d2m_kernel(const KParams<T> p, const int seg_len) {
         constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1);
         const int z = e1 == 0 ? g1 : (e1 > 0 ? g1m : (keep_down ? g1 : g1p));
         const unsigned c = (e1 < 0 && keep_down) ? (unsigned)g0 : col[e0 + 1];
-        pre[q][0] = p.in[(long long)q * p.N + (long long)((unsigned)z * n0 + c)];
+        pre[q][0] = p.in[(long long)q * p.Ni + (long long)((unsigned)z * n0 + c)];
       });
     }
   };
@@ -273,7 +273,7 @@ lbm2d2m_kernel(const KParams<T> p, const int seg_len) {
       sb_rho = keep_rho; sb_j[0] = keep_j[0]; sb_j[1] = keep_j[1]; sb_j[2] = keep_j[2];
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        __builtin_nontemporal_store(f[q][0], p.out + ((long long)q * p.N + (long long)own));
+        __builtin_nontemporal_store(f[q][0], p.out + ((long long)q * p.No + (long long)own));
       });
     }
   };

@@ -144,7 +144,7 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   const int s = p.p_begin + b * seg_len;           // first output plane of this workgroup
 
   const bool in_a = tid < NI;
-  const unsigned pop_bytes = (unsigned)(p.N * (long long)sizeof(T));
+  const unsigned pop_bytes = (unsigned)(p.Ni * (long long)sizeof(T)), pop_bytes_out = (unsigned)(p.No * (long long)sizeof(T));
   const MaskedPlanInfo info = masked_plan_info(p);
   if (tid < kEqCached * S::Q) {
     const int c = tid / S::Q, slot = info.eq_cached[c];
@@ -188,13 +188,13 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
       const int y = e1 == 0 || keep ? g1 : (e1 > 0 ? g1m : g1p);      // source = node - e
       const int x = e0 == 0 || keep ? g0 : (e0 > 0 ? g0m : g0p);
       voff[q] = ((unsigned)y * (unsigned)p.n0 + (unsigned)x) * (unsigned)sizeof(T) + (unsigned)q * pop_bytes;
-      out_off[q] = b_own * (unsigned)sizeof(T) + (unsigned)q * pop_bytes;
+      out_off[q] = b_own * (unsigned)sizeof(T) + (unsigned)q * pop_bytes_out;
     });
   }
   const unsigned plane_nodes = (unsigned)p.n1 * (unsigned)p.n0;
   const unsigned plane_bytes = plane_nodes * (unsigned)sizeof(T);
   const __amdgpu_buffer_rsrc_t in_r = field_rsrc(p.in, (unsigned)S::Q * pop_bytes),
-                               out_r = field_rsrc(p.out, (unsigned)S::Q * pop_bytes);
+                               out_r = field_rsrc(p.out, (unsigned)S::Q * pop_bytes_out);
   const bool abb_a2 = AX == 2 && info.abb_slot != 0;                  // outlet at a plane of the sweep axis
   const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int nbr_lane = (lane - info.abb_side) & 63;                    // AX = 0: who holds the node next to mine

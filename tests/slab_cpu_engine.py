@@ -117,6 +117,20 @@ class OracleSlabEngine:
         self.stream_collide_planes(f, tmp, tau, b - 1, e + 1)
         self.stream_collide_planes(tmp, out, tau, b, e)
 
+    def stream_collide_twice_edges_direct(self, f, out, tau, edge, recv_lower, recv_upper, pack_lower, pack_upper):
+        """lt_stream_collide_twice_edges_direct: the planes beyond the cuts come from the received messages (or, with
+        None, from the ghost planes of f), the outgoing messages are written by the same call"""
+        src = f
+        if recv_lower is not None:
+            src = f.clone()
+            self.unpack_two_step(src, -1, recv_lower)
+            self.unpack_two_step(src, +1, recv_upper)
+        lo, hi = 2, f.shape[1] - 2
+        self.stream_collide_twice_planes(src, out, tau, lo, lo + edge)
+        self.stream_collide_twice_planes(src, out, tau, hi - edge, hi)
+        self.pack_two_step(out, -1, pack_lower)
+        self.pack_two_step(out, +1, pack_upper)
+
     def _sets(self, direction):
         ez = [v[2] for v in self.lat.e]
         return ([q for q in range(self.lat.q) if ez[q] == 0],

@@ -15,9 +15,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def _worker(rank, world, port, res, lattice, collision, steps, dtype_name, out_dir, driver="SlabSimulation"):
+def _worker(rank, world, port, res, lattice, collision, steps, dtype_name, out_dir, driver="SlabSimulation",
+            direct="1"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["LT_SLAB_DIRECT"] = direct
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import lettuce_amd as lt
@@ -68,14 +70,17 @@ def test_slab_ranks_reproduce_single_domain(tmp_path, world, res, lattice, colli
 TWO_STEP_CASES = [(2, [8, 6, 16], 6), (2, [8, 6, 16], 5), (4, [8, 6, 16], 4), (3, [6, 4, 12], 7)]
 
 
+@pytest.mark.parametrize("direct", ["1", "0"], ids=["direct", "edges-beside-interior"])
 @pytest.mark.parametrize("world,res,steps", TWO_STEP_CASES, ids=[f"{c[0]}ranks-{c[2]}steps" for c in TWO_STEP_CASES])
-def test_two_step_slab_ranks_reproduce_single_domain(tmp_path, world, res, steps):
+def test_two_step_slab_ranks_reproduce_single_domain(tmp_path, world, res, steps, direct):
     """The two-step slab driver (two ghost planes, one 19-block message per direction per double
-    step, odd and even numbers of fused steps) on 2-4 gloo ranks against the single-domain oracle."""
+    step, odd and even numbers of fused steps) on 2-4 gloo ranks against the single-domain oracle, with both
+    schedules of a double step: "direct" (edge launch fed from the receive buffers and writing the outgoing messages,
+    then the planes in between) and the edge launches + pack / unpack of rounds 1-2."""
     from oracle import lettuce_oracle as orc
-    port = 29100 + (os.getpid() % 2000) + world + steps
+    port = 29100 + (os.getpid() % 2000) + world + steps + 7 * int(direct)
     mp.spawn(_worker, args=(world, port, res, "D3Q19", "bgk", steps, "float64", str(tmp_path),
-                            "TwoStepSlabSimulation"), nprocs=world, join=True)
+                            "TwoStepSlabSimulation", direct), nprocs=world, join=True)
     got = np.load(tmp_path / "out.npz")
     ref = orc.taylor_green(res, 400, 0.1, "D3Q19", torch.float64, "bgk")
     np.testing.assert_allclose(got["f0"], ref.f.numpy(), rtol=0, atol=2e-15)
@@ -84,7 +89,8 @@ def test_two_step_slab_ranks_reproduce_single_domain(tmp_path, world, res, steps
     assert float(got["ke"]) == pytest.approx(float(orc.kinetic_energy_pu(ref.f, ref.lat, ref.units)), rel=1e-12)
 
 
-def test_two_step_slab_single_rank_and_batches():
+@pytest.mark.parametrize("direct", [True, False], ids=["direct", "edges-beside-interior"])
+def test_two_step_slab_single_rank_and_batches(direct):
     import lettuce_amd as lt
     from slab_cpu_engine import OracleSlabEngine
     from oracle import lettuce_oracle as orc
@@ -93,10 +99,16 @@ def test_two_step_slab_single_rank_and_batches():
     slab = lt.ZSlab(res, rank=0, world_size=1)
     flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 100, 0.1, lt.D3Q19(), slab=slab)
     sim = lt.TwoStepSlabSimulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
-                                   engine=OracleSlabEngine("D3Q19", torch.float64, "bgk"))
+                                   engine=OracleSlabEngine("D3Q19", torch.float64, "bgk"), direct=direct)
+    assert sim._direct_ok() == direct
     ref = orc.taylor_green(res, 100, 0.1, "D3Q19", torch.float64)
     sim(1); sim(2); sim(3); sim(4)
     ref.step(10)
+    np.testing.assert_allclose(sim.gather_f().numpy(), ref.f.numpy(), rtol=0, atol=1e-13)
+    # looking in between (the presentation pass scatters the messages the direct schedule left in the receive
+    # buffers), an odd batch that carries on, then an even one
+    sim(5); _ = sim.local_f(); sim(3); sim(4)
+    ref.step(12)
     np.testing.assert_allclose(sim.gather_f().numpy(), ref.f.numpy(), rtol=0, atol=1e-13)
 
 
