@@ -10,6 +10,8 @@ Workload (BASELINE.json): TaylorGreenVortex3D, D3Q19, BGK, fp32, Re 1600, Ma 0.1
   N > 1   weak scaling at 256^3 = 16.8 M nodes per GPU, z-slab decomposition with RCCL
           ghost-plane exchange: global 512 x 512 x 64N, i.e. every rank holds the 512 x 512 x 64
           slab of BASELINE's configs[2] (N = 8 is exactly its 512^3).
+  --workload cfg5   BASELINE's configs[4] through the same slab path: DoublyPeriodicShear3D D3Q19 fp64,
+          global 384 x 384 x 96N (N = 4 is its 384^3); with N = 1 add --slab.
 A "step" is one full lattice update (collide, stream) of every node.  The timed region is
 exactly K steps between barrier + device synchronise, max over ranks; value = all nodes of all
 ranks * K / time.  One JSON line is printed by rank 0.
@@ -19,9 +21,20 @@ own N ranks (a ``torch.distributed.run`` child process, before this process touc
 relays rank 0's JSON line and the exit code; fewer than N visible devices is an error, never a
 silent N = 1 run.  Under a launcher (WORLD_SIZE set) the process is one rank.
 
-Timing.  Five timed batches of exactly K steps each (barrier + device synchronise on both sides,
-max over ranks); ``ms_per_step`` / ``value`` are those of the median batch, all
-five are listed in ``batches_ms_per_step``.
+Timing.  Five timed batches (barrier + device synchronise on both sides, max over ranks);
+``ms_per_step`` / ``value`` are those of the median batch, all five are listed in
+``batches_ms_per_step``.  A batch is the K-step call repeated R times back to back, R chosen so that
+a batch lasts at least ~50 ms (R = 1 when K steps already do): with the driver's K = 20 a single call
+is 5 ms and one 20 % outlier in five moved the median; ``timing`` states R, ``steps`` stays K and
+every number in the line is per K steps.
+
+N > 1 fails soft.  The slab candidates (driver x transport) are tried one after the other; the first
+one -- the single-step driver over RCCL send/recv -- is timed for its K steps as soon as its warm-up
+probe has finished, and that line is HELD.  A later candidate replaces it only if it is bit-identical to
+it after the warm-up probe AND after its own timed batches, and faster; if one raises, is rejected, or
+exceeds its wall budget (checked on the host between batches; a watchdog thread covers a call that never
+returns), rank 0 still prints the held line with the failure recorded in ``config.transport`` and all ranks
+exit 0.  Nothing is re-executed and no process that has touched the GPU is restarted.
 
 roofline: HBM-bound kernel.  ``achieved`` = the bytes a launch of the dominant kernel has to move
 through HBM -- every population read once and written once, 2 * 19 * 4 = 152 B per node and
@@ -29,21 +42,26 @@ launch, however many lattice updates the launch performs on the
 its average duration, measured with HIP events recorded on the launch stream around the fused
 launches of the median batch.  ``frac`` = achieved / 8 TB/s, a physical HBM fraction (<= 1).  The
 two-step kernel does two lattice updates per launch with the intermediate state in LDS; the rate
-in algorithmic bytes of lattice updates (152 B per node and UPDATE) is reported separately as
-``algorithmic_update_GBps`` and may exceed the HBM peak.  ``traffic`` = HBM bytes per launch from
-the rocprofv3 PMC passes in profiles/traffic.json, used only if that file was produced from the
-kernel sources of this build (hash of lettuce_amd/csrc), else null.
-verified: after the timed batches the same 5 K steps are repeated, untimed, from a copy of the
+in algorithmic bytes of lattice updates (152 B per node and UPDATE, SURVEY 8(d)'s figure) is reported
+as ``algorithmic_update_GBps`` / ``algorithmic_frac`` and may exceed the HBM peak.  ``traffic`` = HBM
+bytes per launch from the rocprofv3 PMC passes in profiles/traffic.json, used only if that file was
+produced from the kernel sources of this build (hash of lettuce_amd/csrc), else null.
+verified: after the timed batches the same steps are repeated, untimed, from a copy of the
 pre-timed populations with the one-step kernel only (``set_two_step(0)``); ``verified`` says
 whether the two final states are bit-identical; final mass and kinetic energy are in the line.
+other_configs (N = 1): BASELINE's configs[3] (Obstacle3D D3Q27 256^3 KBC fp32) and the per-GPU shape of
+configs[4] (shear layer D3Q19 384 x 384 x 96 fp64) through lt.Simulation: kernel, ms per update, physical and
+algorithmic GB/s and a bit-identity flag each (about 15 s; --no-other-configs skips them).
 cpu_baseline: the CPU oracle (a torch-CPU restatement of the reference's path, validated
 against the reference) timed on this box's host cores on the same 256^3 workload for a few
 steps (rank 0, N = 1 only), at all host threads and at 32 threads; the better one is ``value``.
 """
 import argparse
 import json
+import math
 import os
 import sys
+import threading
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
@@ -60,7 +78,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s copy ceiling
-BYTES_PER_NODE = 2 * 19 * 4      # D3Q19 fp32: every population read once, written once
+MIN_BATCH_S = 0.05               # a timed batch lasts at least this long (the K-step call is repeated)
+
+WORKLOADS = {
+    # name: (flow, stencil, dtype, bytes per node and update, per-GPU block when --size 256)
+    "cfg3": ("TaylorGreenVortex3D", "D3Q19", "float32", 2 * 19 * 4, (512, 512, 64)),
+    "cfg5": ("DoublyPeriodicShear3D", "D3Q19", "float64", 2 * 19 * 8, (384, 384, 96)),
+}
 
 
 def parse(argv=None):
@@ -69,22 +93,33 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batches", type=int, default=5,
-                    help="timed batches of --steps steps each; the median one is reported")
+                    help="timed batches; the median one is reported")
     ap.add_argument("--size", type=int, default=256, help="nodes per side of the per-GPU block")
+    ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
+                    help="slab path: cfg3 = TGV D3Q19 fp32, 512 x 512 x 64 per GPU (BASELINE configs[2] at N = 8); "
+                         "cfg5 = shear layer D3Q19 fp64, 384 x 384 x 96 per GPU (configs[4] at N = 4)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1: skip the cfg4 / cfg5-shape rows of the line (profiling passes)")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the untimed re-run with the one-step kernel (profiling passes)")
     ap.add_argument("--no-overlap", action="store_true", help="slab path: exchange without overlap")
     ap.add_argument("--transport", choices=["auto", "all", "rccl", "window"],
                     default=os.environ.get("LT_BENCH_TRANSPORT", "auto"),
                     help="slab path: ghost-plane transport (lettuce_amd/_slab.py).  auto = RCCL send/recv only "
-                         "(both slab drivers are tried in the warm-up, results must be bit-identical, the faster "
-                         "one is timed); all = also the one-sided peer-window transports, which are faster in "
+                         "(both slab drivers; results must be bit-identical); all = also the launch that signals the "
+                         "exchange from inside and the one-sided peer-window transports, which are faster in "
                          "the one-GPU rehearsal but have never run across real xGMI links and end in a device "
                          "trap if a signal is lost -- opt in with --transport all or LT_BENCH_TRANSPORT=all")
     ap.add_argument("--driver", choices=["auto", "single-step", "two-step"], default="auto",
                     help="slab path: restrict the candidates to one slab driver")
+    ap.add_argument("--candidate-budget", type=float, default=float(os.environ.get("LT_BENCH_CANDIDATE_BUDGET", "120")),
+                    help="slab path: wall seconds a candidate after the first may take (checked between batches; "
+                         "a watchdog prints the held line and ends the rank 60 s later if a call never returns)")
+    ap.add_argument("--watchdog-grace", type=float, default=60.0,
+                    help="slab path: seconds past a candidate's budget after which the watchdog prints the held line "
+                         "and ends the rank")
     ap.add_argument("--slab", action="store_true",
                     help="use the z-slab driver (and an RCCL process group) even with one GPU: "
                          "rehearsal of the N > 1 code path")
@@ -177,8 +212,8 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def traffic_from_profile(kernel_name):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+def traffic_from_profile(kernel_name, workload="tgv3d_d3q19_bgk_f32_256"):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes
     (profiles/traffic.json, produced by tools/pmc_traffic.py on the GPU box) -- only if that file
     was measured on a build of the same kernel sources (its ``source_hash``); else null."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -196,7 +231,7 @@ def traffic_from_profile(kernel_name):
         want = core(kernel_name)
         for row in table.get("kernels", []):
             have = core(row.get("kernel", ""))
-            if (row.get("workload") == "tgv3d_d3q19_bgk_f32_256" and row.get("hbm_bytes_per_launch")
+            if (row.get("workload") == workload and row.get("hbm_bytes_per_launch")
                     and have.split("<")[0] == want.split("<")[0]
                     and (want.startswith(have) or have.startswith(want))):
                 return row["hbm_bytes_per_launch"]
@@ -229,6 +264,142 @@ def median_index(values):
     return order[len(order) // 2]
 
 
+def repeats_for(seconds_per_call):
+    """how often the K-step call is repeated inside one timed batch (>= MIN_BATCH_S per batch)"""
+    if seconds_per_call <= 0:
+        return 1
+    return max(1, min(1000, int(math.ceil(MIN_BATCH_S / seconds_per_call))))
+
+
+# ---- N = 1: the other BASELINE configurations -------------------------------------------------
+def other_configs(lt, device):
+    """cfg4 (Obstacle3D D3Q27 256^3 KBC fp32: inlet + anti-bounce-back outlet + sphere) and the per-GPU shape of
+    cfg5 (shear layer D3Q19 384 x 384 x 96 fp64) through lt.Simulation: the kernel lt_run's fused steps use, its
+    time per lattice update (HIP events around the fused launches), physical and algorithmic GB/s, and one
+    bit-identity flag each."""
+    rows = []
+
+    def timed(sim, warm, steps):
+        sim(warm)
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sim._native.fused_events = (e0, e1)
+        t0 = time.perf_counter()
+        sim(steps)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        sim._native.fused_events = None
+        info = sim._native.plan.last_run_info()
+        per_launch = 2 if info["two_step_launches"] else 1
+        launches = info["two_step_launches"] or info["single_step_launches"]
+        return dt, e0.elapsed_time(e1) / max(1, launches), per_launch
+
+    def row(name, flow, sim, steps, dt, launch_ms, per_launch, bytes_per_node, workload_key):
+        n = int(torch.tensor(flow.resolution).prod())
+        kernel = sim._native.plan.kernel_name()
+        physical = bytes_per_node * n / (launch_ms * 1e-3) / 1e9
+        traffic = traffic_from_profile(kernel, workload_key)
+        out = {"config": name, "resolution": list(flow.resolution), "kernel": kernel,
+               "lattice_updates_per_launch": per_launch, "ms_per_update": round(launch_ms / per_launch, 5),
+               "avg_launch_ms": round(launch_ms, 5), "MLUPS_wall": round(steps * n / dt / 1e6, 1),
+               "bytes_per_node_and_update": bytes_per_node,
+               "physical_GBps": round(physical, 1), "physical_frac_of_8TBs": round(physical / HBM_PEAK_GBS, 4),
+               "algorithmic_GBps": round(physical * per_launch, 1),
+               "algorithmic_frac_of_8TBs": round(physical * per_launch / HBM_PEAK_GBS, 4),
+               "traffic": traffic}
+        if traffic:
+            out["hbm_traffic_GBps"] = round(traffic / (launch_ms * 1e-3) / 1e9, 1)
+        return out
+
+    # cfg4
+    ctx = lt.Context(device=device, dtype=torch.float32, use_native=True)
+    flow = lt.Obstacle(ctx, [256, 256, 256], 100, 0.1, domain_length_x=4, stencil=lt.D3Q27())
+    x, y, z = flow.grid
+    flow.mask = ((x - 1) ** 2 + (y - 2) ** 2 + (z - 2) ** 2) < 0.5 ** 2
+    flow.initialize()
+    sim = lt.Simulation(flow, lt.KBCCollision(), [])
+    dt, launch_ms, per_launch = timed(sim, 10, 60)
+    r = row("cfg4: Obstacle3D D3Q27 256^3 KBC fp32, inlet + anti-bounce-back outlet + sphere bounce-back", flow, sim,
+            60, dt, launch_ms, per_launch, 2 * 27 * 4 + 1, "obstacle3d_d3q27_kbc_f32_256")
+    # bit identity: 3 whole steps through lt_run (collide, fused, fused, stream) against collide -> stream three
+    # times through the operator entry points, from the same populations
+    plan = sim._native.plan
+    start = flow.f.clone()
+    tau = float(sim._native.collision.tau(flow))
+    a, b = start.clone(), torch.empty_like(start)
+    for _ in range(3):
+        plan.collide(a, b, tau)
+        plan.stream(b, a)
+    flow.f = start
+    sim(3)
+    same = bool(torch.equal(flow.f, a))
+    r["check"] = {"what": "3 steps of lt.Simulation (fused stream-collide launches) against collide, stream through "
+                          "the operator entry points, torch.equal",
+                  "bit_identical": same, "max_abs_diff": float((flow.f - a).abs().max()),
+                  "finite": bool(torch.isfinite(flow.f).all())}
+    rows.append(r)
+    del sim, flow, plan, start, a, b, x, y, z
+    torch.cuda.empty_cache()
+
+    # cfg5's per-GPU shape
+    ctx = lt.Context(device=device, dtype=torch.float64, use_native=True)
+    flow = lt.DoublyPeriodicShear3D(ctx, [384, 384, 96], 10000, 0.1)
+    sim = lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])
+    dt, launch_ms, per_launch = timed(sim, 10, 60)
+    r = row("cfg5 per-GPU shape: DoublyPeriodicShear3D D3Q19 384 x 384 x 96 BGK fp64", flow, sim, 60, dt, launch_ms,
+            per_launch, 2 * 19 * 8, "shear3d_d3q19_bgk_f64_384x384x96")
+    start = flow.f.clone()
+    sim(5)
+    two = flow.f.clone()
+    info = sim._native.plan.last_run_info()
+    flow.f = start
+    sim._native.plan.set_two_step(0)
+    sim(5)
+    info1 = sim._native.plan.last_run_info()
+    r["check"] = {"what": "5 steps with two updates per launch against the one-step kernel, torch.equal",
+                  "bit_identical": bool(torch.equal(flow.f, two)), "two_step_launches": info["two_step_launches"],
+                  "one_step_run_two_step_launches": info1["two_step_launches"]}
+    rows.append(r)
+    del sim, flow, start, two
+    torch.cuda.empty_cache()
+    return rows
+
+
+# ---- the held line of the N > 1 path ----------------------------------------------------------
+class HeldLine:
+    """The line rank 0 will print, replaced only by better candidates; a watchdog prints it and ends the rank when
+    a candidate call does not return."""
+
+    def __init__(self, rank):
+        self.rank, self.line, self.lock, self.printed = rank, None, threading.Lock(), False
+        self.deadline, self.what = None, ""
+        self._thread = threading.Thread(target=self._watch, daemon=True)
+        self._thread.start()
+
+    def arm(self, seconds, what):
+        self.deadline, self.what = time.time() + seconds, what
+
+    def disarm(self):
+        self.deadline = None
+
+    def emit(self):
+        with self.lock:
+            if self.printed:
+                return
+            self.printed = True
+            if self.rank == 0 and self.line is not None:
+                print(json.dumps(self.line), flush=True)
+
+    def _watch(self):
+        while True:
+            time.sleep(1.0)
+            d = self.deadline
+            if d is not None and time.time() > d and self.line is not None:
+                self.line["config"]["transport"]["aborted"] = f"{self.what}: no return within its budget; held line printed by the watchdog"
+                self.emit()
+                os._exit(0)
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -250,6 +421,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed = world > 1 or args.slab
+    if args.workload != "cfg3" and not distributed:
+        raise SystemExit("--workload cfg5 is a slab workload: use --gpus N (N = 4 is BASELINE's configs[4]) or --slab")
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -257,72 +430,317 @@ def main():
         dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     import lettuce_amd as lt
+    if distributed:
+        return slab_bench(args, lt, dist, world, rank, local_rank, device)
+    single_gpu_bench(args, lt, device)
+
+
+# ---- N = 1 -----------------------------------------------------------------------------------
+def single_gpu_bench(args, lt, device):
+    bytes_per_node = WORKLOADS["cfg3"][3]
     ctx = lt.Context(device=device, dtype=torch.float32, use_native=True)
     n = args.size
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    flow = lt.TaylorGreenVortex(ctx, [n, n, n], 1600, 0.1, lt.D3Q19())
+    sim = lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])
+    nodes = n ** 3
+    kernel = sim._native.plan.kernel_name()
+    resident, resident_stride = sim._native.plan.resident_enabled()
+    sim(args.warmup)
+    # the plain copy rate of this device (roofline.copy_ceiling_GBps) is measured before the timed batches
+    ceiling = copy_ceiling(device)
+    # one more untimed K-step call sizes the batches
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    sim(args.steps)
+    torch.cuda.synchronize(device)
+    repeat = repeats_for(time.perf_counter() - t0)
+    pre_timed = None if args.no_verify else flow.f.clone()   # lettuce's convention: post-streaming
+    sim._native.fused_events = (start, end)
 
-    def barrier():
-        if distributed:
-            dist.barrier(device_ids=[local_rank])
+    batch_s, batch_fused_ms, batch_info = [], [], []
+    for _ in range(max(1, args.batches)):
         torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(repeat):
+            sim(args.steps)
+        torch.cuda.synchronize(device)
+        batch_s.append((time.perf_counter() - t0) / repeat)      # seconds per K steps
+        if args.steps > 1:
+            batch_info.append(sim._native.plan.last_run_info())
+            batch_fused_ms.append(start.elapsed_time(end))       # the fused launches of the batch's last call
+    # lettuce's convention for flow.f is post-streaming; the engine keeps the populations post-collision between
+    # batches and streams when flow.f is read (Flow.f): that one pass, timed here, is what a caller pays per look
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    _ = flow.f
+    torch.cuda.synchronize(device)
+    present_ms = (time.perf_counter() - t0) * 1e3
+    mid = median_index(batch_s)
+    elapsed = batch_s[mid]
+    mlups = args.steps * nodes / 1e6 / elapsed
 
-    if not distributed:
-        flow = lt.TaylorGreenVortex(ctx, [n, n, n], 1600, 0.1, lt.D3Q19())
-        sim = lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])
-        global_res = [n, n, n]
-        nodes_per_rank = n ** 3
-        kernel = sim._native.plan.kernel_name()
-        sim(args.warmup)
-        # the plain copy rate of this device (roofline.copy_ceiling_GBps) is measured before the timed batches
-        ceiling = copy_ceiling(device)
-        pre_timed = None if args.no_verify else flow.f.clone()   # lettuce's convention: post-streaming
-        sim._native.fused_events = (start, end)
-        step = sim
-        parallelism = "single GPU"
-    else:
-        if n == 256:
-            global_res = [512, 512, 64 * world]    # N = 8: BASELINE configs[2] (512^3)
+    roofline, check = None, None
+    if args.steps > 1:
+        # what the events bracketed: the two-step launches (two lattice updates per node each) when
+        # lt_run paired its fused steps, else the single-step launches
+        info = batch_info[mid]
+        paired = info["two_step_launches"] > 0
+        launches = info["two_step_launches"] if paired else info["single_step_launches"]
+        updates_per_launch = 2 if paired else 1
+        fused_ms = batch_fused_ms[mid] / launches
+        hbm_bytes = bytes_per_node * nodes                     # one read + one write of every population
+        achieved = hbm_bytes / (fused_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic_from_profile(kernel),
+                    "kernel": kernel, "avg_launch_ms": round(fused_ms, 5),
+                    "hbm_bytes_per_launch_required": hbm_bytes,
+                    "lattice_updates_per_node_per_launch": updates_per_launch,
+                    "algorithmic_update_GBps": round(achieved * updates_per_launch, 1),
+                    "algorithmic_frac": round(achieved * updates_per_launch / HBM_PEAK_GBS, 4),
+                    "launches_timed": launches, "source_hash": source_hash(),
+                    "populations": (f"engine-owned ping-pong buffers, {resident_stride - nodes} elements of padding between "
+                                    f"populations (lt_resident_*); flow.f / flow.f_next stay the reference's dense "
+                                    f"[q, *res] tensors" if resident else "the caller's dense [q, *res] tensors")}
+        if roofline["traffic"]:
+            # what HBM really carried per second during the launch (PMC bytes / live duration)
+            real = roofline["traffic"] / (fused_ms * 1e-3) / 1e9
+            roofline["hbm_traffic_GBps"] = round(real, 1)
+            roofline["hbm_traffic_frac_of_peak"] = round(real / HBM_PEAK_GBS, 4)
+        roofline["note"] = ("achieved / frac = populations read once + written once per launch / launch time (a physical "
+                            "HBM rate, <= 1)" + ("; the launch performs two lattice updates per node with the intermediate "
+                                                 "state in LDS: algorithmic_update_GBps / algorithmic_frac count SURVEY "
+                                                 "8(d)'s 152 B per node and UPDATE and may exceed the peak"
+                                                 if paired else ""))
+        roofline["copy_ceiling_GBps"] = round(ceiling, 1)
+        roofline["frac_of_copy_ceiling"] = round(achieved / ceiling, 4)
+        # ---- self-check of the timed result (untimed) ------------------------------------------
+        mass = float(sim._native.plan.mass(flow.f))             # device reductions (lt_mass, lt_kinetic_energy)
+        energy = float(lt.IncompressibleKineticEnergy(flow)())
+        checked = len(batch_s) * repeat * args.steps
+        check = {"verified": None, "final_mass_lu": mass, "final_E_pu": energy, "steps_checked": checked}
+        if pre_timed is not None:
+            final = flow.f.clone()
+            flow2 = lt.TaylorGreenVortex(ctx, [n, n, n], 1600, 0.1, lt.D3Q19())
+            flow2.f = pre_timed
+            sim2 = lt.Simulation(flow2, lt.BGKCollision(flow2.units.relaxation_parameter_lu), [])
+            sim2._native.plan.set_two_step(0)                  # one lattice update per launch, the caller's dense buffers
+            sim2(checked)
+            info2 = sim2._native.plan.last_run_info()
+            check["verified"] = bool(torch.equal(flow2.f, final)) and info2["two_step_launches"] == 0
+            check["how"] = ("the same steps repeated from a copy of the pre-timed populations with the one-step "
+                            f"kernel ({sim2._native.plan.kernel_name()}) on dense buffers, torch.equal on all populations")
+            del flow2, sim2, final, pre_timed
+
+    passes = ("K fused stream-collide steps per call, continuing from the post-collision populations of the call before; the "
+              "streaming pass that presents flow.f in lettuce's post-streaming convention runs when flow.f is read (not "
+              "inside the timed batches)")
+    if roofline and roofline.get("lattice_updates_per_node_per_launch", 0) == 2:
+        passes = ("K fused stream-collide steps (K streamings, K collisions) as K/2 two-step launches (+1 single when K "
+                  "is odd), continuing from the post-collision populations of the previous call; the streaming pass "
+                  "that presents flow.f in lettuce's post-streaming convention runs when flow.f is read -- here once, "
+                  "after the timed batches (presentation_pass_ms); ms_per_step_if_read_after_every_batch adds it to "
+                  "every K-step call")
+    line = {
+        "metric": "MLUPS (million lattice updates/s) D3Q19 256³ TGV; achieved HBM GB/s vs peak",
+        "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"TaylorGreenVortex3D D3Q19 BGK fp32 {n}x{n}x{n} ({nodes} nodes per GPU), Re=1600 Ma=0.1",
+                   "global_resolution": [n, n, n], "parallelism": "single GPU", "passes_per_batch": passes},
+        "batches_ms_per_step": [round(t / args.steps * 1e3, 5) for t in batch_s],
+        "timing": (f"median of {len(batch_s)} timed batches; a batch is the {args.steps}-step call repeated {repeat}x back "
+                   f"to back between device synchronisations (>= {int(MIN_BATCH_S * 1e3)} ms per batch), every number is "
+                   f"per {args.steps} steps; the device's plain copy rate (roofline.copy_ceiling_GBps) and one untimed "
+                   f"{args.steps}-step call that sizes the batches come between the warm-up steps and the timed batches"),
+        "repeats_per_batch": repeat,
+        "roofline": roofline,
+        "presentation_pass_ms": round(present_ms, 4),
+        "ms_per_step_if_read_after_every_batch": round((elapsed * 1e3 + present_ms) / args.steps, 5),
+    }
+    if check is not None:
+        line.update(check)
+    del sim, flow
+    torch.cuda.empty_cache()
+    if not args.no_other_configs:
+        try:
+            line["other_configs"] = other_configs(lt, device)
+        except Exception as exc:                       # the headline line must not depend on the extra rows
+            line["other_configs"] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+        torch.cuda.empty_cache()
+    line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(n, args.cpu_baseline_steps)
+    print(json.dumps(line), flush=True)
+
+
+# ---- N > 1 (and the one-GPU rehearsal of that path) -------------------------------------------
+class Ranks:
+    """the collectives the candidate loop needs, on the ranks' devices (RCCL) or on the host (gloo: the CPU test of
+    the loop, tests/test_bench_failsoft.py)"""
+
+    def __init__(self, dist, world, rank, local_rank, device):
+        self.dist, self.world, self.rank, self.local_rank, self.device = dist, world, rank, local_rank, device
+        self.cuda = device.type == "cuda"
+
+    def barrier(self):
+        if self.cuda:
+            self.dist.barrier(device_ids=[self.local_rank])
+            torch.cuda.synchronize(self.device)
         else:
-            global_res = [n, n, n * world]
-        slab = lt.ZSlab(global_res)
+            self.dist.barrier()
 
-        def build(driver, transport):
+    def all_ranks(self, flag: bool) -> bool:
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def max_over_ranks(self, seconds: float) -> float:
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, value: float):
+        mine = torch.tensor([value], dtype=torch.float64, device=self.device)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [round(float(x.item()), 6) for x in out]
+
+    def release(self):
+        if self.cuda:
+            torch.cuda.empty_cache()
+
+
+def slab_bench(args, lt, dist, world, rank, local_rank, device):
+    flow_name, stencil_name, dtype_name, bytes_per_node, block = WORKLOADS[args.workload]
+    dtype = getattr(torch, dtype_name)
+    ctx = lt.Context(device=device, dtype=dtype, use_native=True)
+    n = args.size
+    if n == 256:
+        global_res = [block[0], block[1], block[2] * world]    # cfg3: N = 8 is BASELINE configs[2] (512^3)
+    else:
+        global_res = [n, n, n * world]
+    slab = lt.ZSlab(global_res)
+    nodes_per_rank = global_res[0] * global_res[1] * slab.nz_local
+    ranks = Ranks(dist, world, rank, local_rank, device)
+
+    def build(driver, transport):
+        if args.workload == "cfg5":
+            flow = lt.DoublyPeriodicShear3D(ctx, slab.extended_resolution, 10000, 0.1, slab=slab)
+        else:
             flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 1600, 0.1, lt.D3Q19(), slab=slab)
-            coll = lt.BGKCollision(flow.units.relaxation_parameter_lu)
-            if driver == "two-step":
-                # "window-fused": edge launches store into the neighbour's window themselves, one stream
-                # "rccl-signalled": one launch per double step whose edge workgroups run first and release the exchange
-                return lt.TwoStepSlabSimulation(flow, coll, slab, overlap=not args.no_overlap,
-                                                transport=transport.split("-")[0],
-                                                fused_remote_pack=transport.endswith("-fused"),
-                                                signalled=transport.endswith("-signalled"))
-            return lt.SlabSimulation(flow, coll, slab, overlap=not args.no_overlap, transport=transport)
+        coll = lt.BGKCollision(flow.units.relaxation_parameter_lu)
+        if driver == "two-step":
+            # "rccl": the direct schedule (edge launch fed from the receive buffers, then the planes in between)
+            # "rccl-edges": edge launches + pack / unpack beside the interior launch (rounds 1-2)
+            # "rccl-signalled": one launch per double step whose edge workgroups run first and release the exchange
+            # "window-fused": edge launches store into the neighbour's window themselves, one stream
+            return lt.TwoStepSlabSimulation(flow, coll, slab, overlap=not args.no_overlap,
+                                            transport=transport.split("-")[0],
+                                            fused_remote_pack=transport.endswith("-fused"),
+                                            signalled=transport.endswith("-signalled"),
+                                            direct=transport == "rccl")
+        return lt.SlabSimulation(flow, coll, slab, overlap=not args.no_overlap, transport=transport)
 
-        def all_ranks(flag: bool) -> bool:
-            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return bool(t.item())
+    # Candidates: slab driver (two lattice updates per launch and one halo exchange per two updates / one update per
+    # launch) x transport.  The single-step driver over RCCL comes first and is the reference: see the module
+    # docstring ("N > 1 fails soft").
+    transports = {"auto": ["rccl"], "all": ["rccl", "window"]}.get(args.transport, [args.transport])
+    drivers = ["two-step", "single-step"] if args.driver == "auto" else [args.driver]
+    wanted = [(d, t) for d in drivers for t in transports]
+    if args.transport == "all" and "two-step" in drivers and not args.no_overlap:
+        at = wanted.index(("two-step", "rccl")) + 1
+        wanted[at:at] = [("two-step", "rccl-edges"), ("two-step", "rccl-signalled")]
+    if "two-step" in drivers and "window" in transports:
+        wanted.insert(wanted.index(("two-step", "window")) + 1, ("two-step", "window-fused"))
+    if ("single-step", "rccl") in wanted:
+        wanted = [("single-step", "rccl")] + [w for w in wanted if w != ("single-step", "rccl")]
 
-        # Candidates: slab driver (two lattice updates per launch and one halo exchange per two
-        # updates / one update per launch) x transport (RCCL send/recv / one-sided peer windows).
-        # The single-step driver over RCCL is the reference: every candidate does 3 + W warm-up
-        # steps from the same initial state (two timed batches of max(W, 60) steps, max over ranks), must end with populations
-        # bit-identical to the reference's on every rank, and the fastest eligible one runs the
-        # timed K steps.  All warm-up rates go into the JSON line.
-        transports = {"auto": ["rccl"], "all": ["rccl", "window"]}.get(args.transport, [args.transport])
-        drivers = ["two-step", "single-step"] if args.driver == "auto" else [args.driver]
-        wanted = [(d, t) for d in drivers for t in transports]
-        if "two-step" in drivers and "rccl" in transports and not args.no_overlap:
-            wanted.insert(wanted.index(("two-step", "rccl")) + 1, ("two-step", "rccl-signalled"))
-        if "two-step" in drivers and "window" in transports:
-            wanted.insert(wanted.index(("two-step", "window")) + 1, ("two-step", "window-fused"))
-        if args.driver == "auto" and args.transport in ("auto", "all"):
-            wanted = [("single-step", "rccl")] + [w for w in wanted if w != ("single-step", "rccl")]
-        finals, probe = {}, {}
-        window_ok = None
-        probe_steps = max(args.warmup, 60)
-        for driver, transport in wanted:
-            name = f"{driver}/{transport}"
+    what = (f"{flow_name} {stencil_name} BGK {'fp32' if dtype == torch.float32 else 'fp64'} "
+            f"{global_res[0]}x{global_res[1]}x{global_res[2]} ({nodes_per_rank} nodes per GPU)")
+    candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank, bytes_per_node,
+                   "f32" if dtype == torch.float32 else "f64")
+    dist.barrier(device_ids=[local_rank])
+    dist.destroy_process_group()
+
+
+def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank, bytes_per_node, dtype_tag,
+                   probe_steps=None):
+    """Try the candidates in order, time each one that passes its checks, hold the best line; rank 0 prints the held
+    line at the end -- or the watchdog does -- whatever the later candidates did.  ``build(driver, transport)``
+    returns a slab driver (callable with a step count, ``local_f()``, ``engine.kernel_name()``)."""
+    world, rank, device = ranks.world, ranks.rank, ranks.device
+    barrier, all_ranks, max_over_ranks = ranks.barrier, ranks.all_ranks, ranks.max_over_ranks
+    held = HeldLine(rank)
+    probe, checks, failures = {}, {}, {}
+    reference = {}                     # the first candidate's populations after the probe and after its timed batches
+    probe_steps = max(args.warmup, 60) if probe_steps is None else probe_steps
+    window_ok = None
+
+    def describe(driver, transport):
+        how = {"rccl": "RCCL send/recv of the halo messages",
+               "rccl-edges": "RCCL send/recv ghost planes; edge launches, pack and unpack beside the interior launch",
+               "rccl-signalled": "RCCL send/recv ghost planes, released by the edge workgroups of the one launch per double step",
+               }.get(transport, "one-sided ghost-plane stores into peer windows (xGMI peer access)"
+                     + (", issued by the edge launches" if transport.endswith("-fused") else ""))
+        if driver == "two-step" and transport == "rccl":
+            how += (" straight out of / into the buffers the edge launch writes / reads (no pack, no unpack); edge launch, "
+                    "then the planes in between, on one stream")
+        how += ("; two lattice updates per launch, one exchange per two updates" if driver == "two-step"
+                else "; one exchange per update")
+        return f"z-slab x{world}, {how}" + ("" if not args.no_overlap else " (no overlap)")
+
+    def make_line(name, driver, transport, batch_s, repeat, kernel, verified):
+        mid = median_index(batch_s)
+        elapsed = batch_s[mid]
+        mlups = args.steps * nodes_per_rank * world / 1e6 / elapsed
+        # per-rank fused-kernel rate is not separable from the exchange here: the whole-step rate of one rank.
+        # achieved = bytes HBM has to carry (populations read once + written once per LAUNCH; the two-step driver
+        # does two lattice updates per launch) / time, a physical rate like the N = 1 line's
+        eff = bytes_per_node * nodes_per_rank * args.steps / elapsed / 1e9
+        per_launch = 2 if driver == "two-step" else 1
+        roofline = {"bound": "hbm", "achieved": round(eff / per_launch, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(eff / per_launch / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
+                    "lattice_updates_per_node_per_launch": per_launch, "algorithmic_update_GBps": round(eff, 1),
+                    "algorithmic_frac": round(eff / HBM_PEAK_GBS, 4),
+                    "note": "whole-step rate per GPU (includes the halo exchange): populations read once + written once "
+                            f"per launch / time; algorithmic_update_GBps counts {bytes_per_node} B per node and update"}
+        return {
+            "metric": "MLUPS (million lattice updates/s) D3Q19 256³ TGV; achieved HBM GB/s vs peak",
+            "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": dtype_tag, "data": "synthetic",
+            "config": {"workload": what, "global_resolution": global_res, "parallelism": describe(driver, transport),
+                       "passes_per_batch": "K fused stream-collide steps per call, continuing from the post-collision "
+                                           "populations (ghost planes exchanged) of the call before; the streaming pass "
+                                           "that presents the populations in lettuce's post-streaming convention runs "
+                                           "when they are read (not inside the timed batches)",
+                       "transport": {"chosen": name, "warmup_ms_per_step": probe, "checks": checks,
+                                     "failures": failures, "ranks_seen": world}},
+            "batches_ms_per_step": [round(t / args.steps * 1e3, 5) for t in batch_s],
+            "timing": (f"median of {len(batch_s)} timed batches (barrier + device synchronise on both sides, max over "
+                       f"ranks); a batch is the {args.steps}-step call repeated {repeat}x back to back "
+                       f"(>= {int(MIN_BATCH_S * 1e3)} ms per batch), every number is per {args.steps} steps"),
+            "repeats_per_batch": repeat,
+            "roofline": roofline,
+            "verified": verified,
+            "cpu_baseline": None,
+        }
+
+    for index, (driver, transport) in enumerate(wanted):
+        name = f"{driver}/{transport}"
+        first = index == 0
+        started = time.time()
+        budget = None if first else args.candidate_budget
+        if budget is not None:
+            held.arm(budget + args.watchdog_grace, name)
+
+        def over_budget():
+            """between batches: has ANY rank used up this candidate's wall budget?  (collective)"""
+            return budget is not None and not all_ranks(time.time() - started <= budget)
+
+        try:
             if transport.startswith("window"):
                 if window_ok is None:
                     # preflight on every rank before the collective rendezvous inside build(): a rank
@@ -333,217 +751,118 @@ def main():
                         ok = True
                     except Exception as exc:
                         ok = False
-                        probe[name] = f"unavailable: {type(exc).__name__}: {str(exc)[:120]}"
+                        failures[name] = f"unavailable: {type(exc).__name__}: {str(exc)[:120]}"
                     window_ok = all_ranks(ok)
                 if not window_ok:
-                    probe.setdefault(name, "unavailable: no peer-mappable memory on some rank")
+                    failures.setdefault(name, "unavailable: no peer-mappable memory on some rank")
                     continue
+            # ---- build + connection set-up ----
+            cand, err = None, None
             try:
                 cand = build(driver, transport)
                 cand(3)                         # connection set-up, first launches: not timed
-                ok = True
             except Exception as exc:            # unsupported grid for the two-step kernel, no symmetric memory ...
-                cand, ok = None, False
-                probe[name] = f"unavailable: {type(exc).__name__}: {str(exc)[:120]}"
-            if not all_ranks(ok):
-                probe.setdefault(name, "unavailable on another rank")
+                err = f"unavailable: {type(exc).__name__}: {str(exc)[:120]}"
+            if not all_ranks(err is None):
+                failures[name] = err or "unavailable on another rank"
                 cand = None
+                ranks.release()
                 continue
-            best, failed = None, None
-            for _ in range(2):                  # two batches of >= 60 steps, the faster one counts
+            # ---- warm-up probe: two batches of >= 60 steps, the faster one counts ----
+            best, err = None, None
+            for _ in range(2):
                 barrier()
                 t0 = time.perf_counter()
                 try:
                     cand(probe_steps)
                 except Exception as exc:        # e.g. the signalled driver's time-out: raised after the batch's
-                    failed = f"failed: {type(exc).__name__}: {str(exc)[:120]}"   # exchanges, so the ranks stay in step
+                    err = f"failed: {type(exc).__name__}: {str(exc)[:120]}"   # exchanges, so the ranks stay in step
                 barrier()
-                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                best = float(t.item()) if best is None else min(best, float(t.item()))
-            if not all_ranks(failed is None):
-                probe[name] = failed or "failed on another rank"
+                t = max_over_ranks(time.perf_counter() - t0)
+                best = t if best is None else min(best, t)
+                if not all_ranks(err is None) or over_budget():
+                    err = err or "failed on another rank / over its wall budget"
+                    break
+            if err is not None:
+                failures[name] = err
                 cand = None
-                torch.cuda.empty_cache()
+                ranks.release()
                 continue
             probe[name] = round(best / probe_steps * 1e3, 5)
-            # keep only the final populations; candidates must not share the device while timed
-            finals[name] = cand.local_f().clone()
-            cand = None
-            torch.cuda.empty_cache()
-        if not finals:
-            raise SystemExit(f"no usable slab configuration: {probe}")
-        reference = finals.get("single-step/rccl")
-        checks, eligible = {}, []
-        for name, state in finals.items():
-            if reference is not None and state is not reference:
-                same = all_ranks(torch.equal(state, reference))
-                checks[name] = "bit-identical to single-step/rccl" if same else "MISMATCH: rejected"
+            state = cand.local_f()
+            if first:
+                reference["probe"] = state.clone()
+            elif "probe" in reference:
+                same = all_ranks(torch.equal(state, reference["probe"]))
+                checks[name] = f"bit-identical to {wanted[0][0]}/{wanted[0][1]} after the warm-up probe" if same else "MISMATCH after the warm-up probe: rejected"
                 if not same:
+                    cand = None
+                    ranks.release()
                     continue
-            eligible.append(name)
-        chosen = min(eligible, key=lambda k: probe[k])
-        # what every rank ended the warm-up with, for the record: RCCL really saw `world` ranks, each
-        # with its own slab (sum of the populations of the chosen candidate, per rank)
-        mine = torch.tensor([float(finals[chosen].double().sum())], dtype=torch.float64, device=device)
-        sums = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(sums, mine)
-        rank_checksums = [round(float(x.item()), 6) for x in sums]
-        finals.clear()
-        reference = state = None
-        torch.cuda.empty_cache()
-        driver, transport = chosen.split("/")
-        sim = build(driver, transport)              # fresh instance of the chosen configuration
-        sim(args.warmup)
-        nodes_per_rank = global_res[0] * global_res[1] * slab.nz_local
-        kernel = sim.engine.kernel_name()
-        step = sim
-        how = ("RCCL send/recv ghost planes" if transport == "rccl"
-               else "RCCL send/recv ghost planes, released by the edge workgroups of the one launch per double step"
-               if transport == "rccl-signalled"
-               else "one-sided ghost-plane stores into peer windows (xGMI peer access)"
-               + (", issued by the edge launches" if transport.endswith("-fused") else ""))
-        how += ("; two lattice updates per launch, one exchange per two updates" if driver == "two-step"
-                else "; one exchange per update")
-        parallelism = f"z-slab x{world}, {how}" + ("" if not args.no_overlap else " (no overlap)")
-        transport_info = {"chosen": chosen, "warmup_ms_per_step": probe, "checks": checks,
-                          "ranks_seen": world, "rank_checksums_after_warmup": rank_checksums}
+            del state
+            # ---- the timed region: W more warm-up steps, then `batches` times (R x) exactly K steps ----
+            cand(args.warmup)
+            barrier()
+            t0 = time.perf_counter()
+            cand(args.steps)                    # sizes the batches (untimed)
+            barrier()
+            repeat = repeats_for(max_over_ranks(time.perf_counter() - t0))
+            batch_s, err = [], None
+            for _ in range(max(1, args.batches)):
+                barrier()
+                t0 = time.perf_counter()
+                try:
+                    for _ in range(repeat):
+                        cand(args.steps)
+                except Exception as exc:
+                    err = f"failed in the timed batches: {type(exc).__name__}: {str(exc)[:120]}"
+                barrier()
+                batch_s.append(max_over_ranks(time.perf_counter() - t0) / repeat)
+                if not all_ranks(err is None) or over_budget():
+                    err = err or "failed on another rank / over its wall budget"
+                    break
+            if err is not None:
+                failures[name] = err
+                cand = None
+                ranks.release()
+                continue
+            # ---- after the timed batches: the same number of steps as the reference candidate has done ----
+            state = cand.local_f()
+            verified = None
+            if first:
+                reference["final"] = state.clone()
+                reference["repeat"] = repeat
+            elif "final" in reference and reference["repeat"] == repeat:
+                verified = all_ranks(torch.equal(state, reference["final"]))
+                checks[name] += ("; bit-identical after the timed batches too" if verified
+                                 else "; MISMATCH after the timed batches: rejected")
+                if not verified:
+                    cand = None
+                    ranks.release()
+                    continue
+            # what every rank ended with, for the record: RCCL really saw `world` ranks, each with its own slab
+            sums = ranks.gather(float(state.double().sum()))
+            del state
+            kernel = cand.engine.kernel_name() if hasattr(cand.engine, "kernel_name") else type(cand.engine).__name__
+            line = make_line(name, driver, transport, batch_s, repeat, kernel, verified)
+            line["config"]["transport"]["rank_checksums"] = sums
+            if held.line is None or line["value"] > held.line["value"]:
+                held.line = line
+            else:
+                checks[name] = checks.get(name, "") + "; not faster than the held line"
+            cand = None
+            ranks.release()
+        except Exception as exc:                # anything unforeseen in a candidate must not cost the held line
+            failures[name] = f"failed: {type(exc).__name__}: {str(exc)[:160]}"
+            if first:
+                raise
+        finally:
+            held.disarm()
 
-    # ---- the timed region: `batches` times exactly K steps, each between barrier + synchronise ----
-    batch_s, batch_fused_ms, batch_info = [], [], []
-    for _ in range(max(1, args.batches)):
-        barrier()
-        t0 = time.perf_counter()
-        step(args.steps)
-        barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-        if distributed:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        batch_s.append(float(t.item()))
-        if not distributed and args.steps > 1:
-            info = sim._native.plan.last_run_info()
-            batch_info.append(info)
-            batch_fused_ms.append(start.elapsed_time(end))
-    # lettuce's convention for flow.f is post-streaming; the engine keeps the populations post-collision between
-    # batches and streams when flow.f is read (Flow.f): that one pass, timed here, is what a caller pays per look
-    present_ms = None
-    if not distributed:
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        _ = flow.f
-        torch.cuda.synchronize(device)
-        present_ms = (time.perf_counter() - t0) * 1e3
-    mid = median_index(batch_s)
-    elapsed = batch_s[mid]
-    total_nodes = nodes_per_rank * world
-    mlups = args.steps * total_nodes / 1e6 / elapsed
-
-    roofline = None
-    check = None
-    if not distributed and args.steps > 1:
-        # what the events bracketed: the two-step launches (two lattice updates per node each) when
-        # lt_run paired its fused steps, else the single-step launches
-        info = batch_info[mid]
-        paired = info["two_step_launches"] > 0
-        launches = info["two_step_launches"] if paired else info["single_step_launches"]
-        updates_per_launch = 2 if paired else 1
-        fused_ms = batch_fused_ms[mid] / launches
-        hbm_bytes = BYTES_PER_NODE * nodes_per_rank            # one read + one write of every population
-        achieved = hbm_bytes / (fused_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic_from_profile(kernel),
-                    "kernel": kernel, "avg_launch_ms": round(fused_ms, 5),
-                    "hbm_bytes_per_launch_required": hbm_bytes,
-                    "lattice_updates_per_node_per_launch": updates_per_launch,
-                    "algorithmic_update_GBps": round(achieved * updates_per_launch, 1),
-                    "launches_timed": launches, "source_hash": source_hash()}
-        if roofline["traffic"]:
-            # what HBM really carried per second during the launch (PMC bytes / live duration)
-            real = roofline["traffic"] / (fused_ms * 1e-3) / 1e9
-            roofline["hbm_traffic_GBps"] = round(real, 1)
-            roofline["hbm_traffic_frac_of_peak"] = round(real / HBM_PEAK_GBS, 4)
-        roofline["note"] = ("achieved = populations read once + written once per launch / launch time (a physical "
-                            "HBM rate)" + ("; the launch performs two lattice updates per node with the intermediate "
-                                           "state in LDS, algorithmic_update_GBps counts 152 B per node and update"
-                                           if paired else ""))
-        roofline["copy_ceiling_GBps"] = round(ceiling, 1)
-        roofline["frac_of_copy_ceiling"] = round(achieved / ceiling, 4)
-        # ---- self-check of the timed result (untimed) ------------------------------------------
-        mass = float(sim._native.plan.mass(flow.f))             # device reductions (lt_mass, lt_kinetic_energy)
-        energy = float(lt.IncompressibleKineticEnergy(flow)())
-        check = {"verified": None, "final_mass_lu": mass, "final_E_pu": energy,
-                 "steps_checked": len(batch_s) * args.steps}
-        if pre_timed is not None:
-            final = flow.f.clone()
-            flow2 = lt.TaylorGreenVortex(ctx, [n, n, n], 1600, 0.1, lt.D3Q19())
-            flow2.f = pre_timed
-            sim2 = lt.Simulation(flow2, lt.BGKCollision(flow2.units.relaxation_parameter_lu), [])
-            sim2._native.plan.set_two_step(0)                  # one lattice update per launch
-            sim2(len(batch_s) * args.steps)
-            info2 = sim2._native.plan.last_run_info()
-            check["verified"] = bool(torch.equal(flow2.f, final)) and info2["two_step_launches"] == 0
-            check["how"] = ("the same steps repeated from a copy of the pre-timed populations with the one-step "
-                            f"kernel ({sim2._native.plan.kernel_name()}), torch.equal on all populations")
-            del flow2, sim2, final, pre_timed
-    elif distributed:
-        # per-rank fused-kernel rate is not separable from the exchange here: the whole-step rate of one rank.
-        # achieved = bytes HBM has to carry (populations read once + written once per LAUNCH; the two-step
-        # driver does two lattice updates per launch) / time, a physical rate like the N = 1 line's
-        eff = BYTES_PER_NODE * nodes_per_rank * args.steps / elapsed / 1e9
-        per_launch = 2 if driver == "two-step" else 1
-        roofline = {"bound": "hbm", "achieved": round(eff / per_launch, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(eff / per_launch / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
-                    "lattice_updates_per_node_per_launch": per_launch, "algorithmic_update_GBps": round(eff, 1),
-                    "note": "whole-step rate per GPU (includes halo exchange and the collide/stream passes of the "
-                            "batch): populations read once + written once per launch / time; "
-                            "algorithmic_update_GBps counts 152 B per node and update"}
-
-    passes = ("K fused stream-collide steps per batch, continuing from the post-collision populations (ghost planes "
-              "exchanged) of the batch before; the streaming pass that presents the populations in lettuce's "
-              "post-streaming convention runs when they are read (not inside the timed batches)")
-    if roofline and roofline.get("lattice_updates_per_node_per_launch", 0) == 2:
-        # the timed call continues from the post-collision state the warm-up call left (lt_continue)
-        passes = ("K fused stream-collide steps (K streamings, K collisions) as K/2 two-step launches (+1 single when K "
-                  "is odd), continuing from the post-collision populations of the previous batch; the streaming pass "
-                  "that presents flow.f in lettuce's post-streaming convention runs when flow.f is read -- here once, "
-                  "after the timed batches (presentation_pass_ms); ms_per_step_if_read_after_every_batch adds it to "
-                  "every batch")
-    if rank == 0:
-        line = {
-            "metric": "MLUPS (million lattice updates/s) D3Q19 256³ TGV; achieved HBM GB/s vs peak",
-            "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"TaylorGreenVortex3D D3Q19 BGK fp32 "
-                                   f"{global_res[0]}x{global_res[1]}x{global_res[2]} "
-                                   f"({nodes_per_rank} nodes per GPU), Re=1600 Ma=0.1",
-                       "global_resolution": global_res, "parallelism": parallelism,
-                       "passes_per_batch": passes},
-            "batches_ms_per_step": [round(t / args.steps * 1e3, 5) for t in batch_s],
-            "timing": f"median of {len(batch_s)} timed batches of {args.steps} steps"
-                      + ("" if distributed else "; the device's plain copy rate (roofline.copy_ceiling_GBps) is measured "
-                         "between the warm-up steps and the timed batches"),
-            "roofline": roofline,
-        }
-        if present_ms is not None:
-            line["presentation_pass_ms"] = round(present_ms, 4)
-            line["ms_per_step_if_read_after_every_batch"] = round((elapsed * 1e3 + present_ms) / args.steps, 5)
-        if check is not None:
-            line.update(check)
-        if distributed:
-            line["config"]["transport"] = transport_info
-        if not distributed and not args.no_cpu_baseline:
-            del sim, flow
-            torch.cuda.empty_cache()
-            line["cpu_baseline"] = cpu_baseline(n, args.cpu_baseline_steps)
-        else:
-            line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
-    if distributed:
-        dist.barrier(device_ids=[local_rank])
-        dist.destroy_process_group()
+    if held.line is None:
+        raise SystemExit(f"no usable slab configuration: {failures}")
+    held.emit()
+    reference.clear()
 
 
 if __name__ == "__main__":

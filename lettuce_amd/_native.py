@@ -247,6 +247,7 @@ class Plan:
         self.n_boundaries = len(boundaries)
 
     # ------------------------------------------------------------------ helpers
+    @_on_device
     def _fill_boundary(self, out: _BoundaryDesc, b: dict, index: int):
         out.kind = BOUNDARY_KINDS[b["kind"]]
         out.axis = int(b.get("axis", 0))

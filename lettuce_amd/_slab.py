@@ -634,7 +634,12 @@ class TwoStepSlabSimulation(SlabSimulation):
         interior = self.hi - self.lo - 2 * self.edge_planes
         if self._signalled:
             interior = -(-(self.hi - self.lo - 2) // 4) * 4     # the one launch sweeps all planes but the upper edge
-        seg = int(os.environ.get("LT_SLAB_RCCL_SEGMENT", str(interior // 4 if interior >= 32 else 0)))
+        # The direct schedule runs its launches one after the other on one stream, and the exchange needs no launch
+        # of its own besides RCCL's copy, which finds a free compute unit when the edge launch retires: one segment per
+        # tile (the engine's choice) is best there -- 512 x 512 x 64, self exchange: 0.307 ms per step against 0.315 /
+        # 0.318 / 0.323 with segments of 30 / 20 / 15 planes (profiles/r03_slab_direct_probe.txt).
+        default = 0 if self._direct_ok() else (interior // 4 if interior >= 32 else 0)
+        seg = int(os.environ.get("LT_SLAB_RCCL_SEGMENT", str(default)))
         if seg > 0 and self._window is None and hasattr(self.engine, "set_two_step"):
             self.engine.set_two_step(1, seg)
 

@@ -281,19 +281,24 @@ int resolve_lds(const lt_plan *p, long long workgroups) {
 // Distance added between consecutive populations of the engine's own buffers.  The q read streams and q write
 // streams of a node advance in lockstep; with the populations a power of two apart (256^3 fp32: exactly 64 MiB)
 // they meet in the same memory channels.  Measured on MI355X (tools/pad_sweep_probe.py).
-long long default_pad(const lt_plan *p) {
-  return 2368 / p->esize * 4;       // bytes: 9472 = 37 * 256 -- an odd number of 256-byte channel units
-}
+// Of the pads tried on five 3-D grids and three lattices (0, 128, 320, 2112, 2368, 32832 elements, three runs
+// each) 32768 + 64 elements was the best or within a per cent of the best everywhere: two-step launch -7.0 % at
+// 256^3 fp32 (populations exactly 64 MiB apart when dense), -2.3 % at 512 x 512 x 64, -5.1 % at 256 x 256 x 512,
+// -4.9 % at 384^3, -5.2 % at 256^3 fp64, -3.9 % for D3Q15 (profiles/r03_pad_sweep_robust.jsonl).
+long long default_pad(const lt_plan *) { return 32768 + 64; }
 long long resident_stride(const lt_plan *p) {
   const long long pad = p->res_pad >= 0 ? p->res_pad : default_pad(p);
   const long long unit = 256 / p->esize;                      // keep every population 256-byte aligned
   return (p->N + pad + unit - 1) / unit * unit;
 }
+bool two_step_wanted(lt_plan *p);
 bool resident_wanted(const lt_plan *p) {
   if (p->desc.ghost_planes || p->unit.d < 2) return false;
   if (p->resident >= 0) return p->resident != 0;
-  // automatic: the streaming regime (populations beyond the caches), where the launches are bound by HBM
-  return 2ll * p->unit.q * p->N * p->esize > (128ll << 20);
+  // automatic: 3-D plans whose fused steps run as two-step launches (which implies the streaming regime).  The
+  // one-step kernels stream best from DENSE populations (padding costs them 2-4 %: 256^3 D3Q19 fp32 0.411 ->
+  // 0.42-0.44 ms) and D2Q9's two-step kernel gains nothing (4096^2: -2 % .. +4 %), so those keep the caller's buffers.
+  return p->unit.d == 3 && two_step_wanted(const_cast<lt_plan *>(p));
 }
 int resident_alloc(lt_plan *p) {
   const long long stride = resident_stride(p);
@@ -588,7 +593,7 @@ bool two_step_possible(lt_plan *p, const char **why) {
     return false;
   }
   // with masks the whole (padded) field is addressed with 32-bit offsets
-  const long long widest = std::max(pop_stride_of(p), resident_wanted(p) ? resident_stride(p) : 0ll);
+  const long long widest = std::max(pop_stride_of(p), p->resident != 0 ? resident_stride(p) : 0ll);
   if (!two_step_addressable(p->unit.d, p->unit.q, p->esize, p->n0, p->n1, p->n2, p->masked != 0) ||
       (p->masked && p->unit.d == 3 && (long long)p->unit.q * widest * p->esize >= (1ll << 32))) {
     *why = p->masked ? "with boundaries the two-step kernel addresses the field with 32-bit offsets: q * nodes * sizeof(scalar) "

@@ -171,7 +171,7 @@ lbm2d2m_kernel(const KParams<T> p, const int seg_len) {
 
   const MaskedPlanInfo info = masked_plan_info(p);
   if (tid < kEqCached * S::Q) {
-    const int c = tid / S::Q, slot = info.eq_cached[c];
+    const int c = tid / S::Q, slot = c == 0 ? info.eq0 : info.eq1;
     lds_feq[c][tid - c * S::Q] = slot ? p.bt->feq[slot][tid - c * S::Q] : T(0);
   }
   lds_barrier();
@@ -196,8 +196,8 @@ lbm2d2m_kernel(const KParams<T> p, const int seg_len) {
             constexpr int q = decltype(qc)::value;
             g[q][0] = fld[(long long)q * p.N + own];
           });
-        } else if (bidx == info.eq_cached[0] || bidx == info.eq_cached[1]) {
-          const int c = bidx == info.eq_cached[0] ? 0 : 1;
+        } else if (bidx == info.eq0 || bidx == info.eq1) {
+          const int c = bidx == info.eq0 ? 0 : 1;
           static_for<S::Q>([&](auto qc) { g[decltype(qc)::value][0] = lds_feq[c][decltype(qc)::value]; });
         } else {
           static_for<S::Q>([&](auto qc) { g[decltype(qc)::value][0] = p.bt->feq[bidx][decltype(qc)::value]; });

@@ -82,19 +82,23 @@ constexpr size_t two_step_masked_lds() {
 struct MaskedPlanInfo {
   unsigned kinds;
   unsigned fields;                  // bit s: equilibrium boundary s has a per-node field
-  int eq_cached[kEqCached];         // the first uniform equilibrium boundaries: their populations sit in LDS (0: none)
+  int eq0, eq1;                     // the first two uniform equilibrium boundaries: their populations sit in LDS (0: none).
+                                    // Two scalars, not an array: an array indexed by a variable makes the whole struct
+                                    // an alloca, which hipcc "promotes" to 32 bytes of LDS per thread and reads back
+                                    // into VECTOR registers -- every test on the plan then looks divergent
   int abb_slot, abb_side, abb_plane, abb_axis;
 };
 template <typename T>
 __device__ __forceinline__ MaskedPlanInfo masked_plan_info(const KParams<T> &p) {
-  MaskedPlanInfo m = {0u, 0u, {0, 0}, 0, 1, -1, 2};
+  MaskedPlanInfo m = {0u, 0u, 0, 0, 0, 1, -1, 2};
   int cached = 0;
   for (int slot = 1; slot <= p.nb; ++slot) {
     const int kind = p.bt->kind[slot];
     m.kinds |= (unsigned)kind << (2 * slot);
     if (kind == kEquilibrium) {
       if (p.bt->field[slot]) m.fields |= 1u << slot;
-      else if (cached < kEqCached) m.eq_cached[cached++] = slot;
+      else if (cached == 0) { m.eq0 = slot; cached = 1; }
+      else if (cached == 1) { m.eq1 = slot; cached = 2; }
     }
     if (kind == kAbbOutlet) {
       m.abb_slot = slot; m.abb_side = p.bt->side[slot]; m.abb_plane = p.bt->plane[slot];
@@ -147,7 +151,7 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   const unsigned pop_bytes = (unsigned)(p.Ni * (long long)sizeof(T)), pop_bytes_out = (unsigned)(p.No * (long long)sizeof(T));
   const MaskedPlanInfo info = masked_plan_info(p);
   if (tid < kEqCached * S::Q) {
-    const int c = tid / S::Q, slot = info.eq_cached[c];
+    const int c = tid / S::Q, slot = c == 0 ? info.eq0 : info.eq1;
     lds_feq[c][tid - c * S::Q] = slot ? p.bt->feq[slot][tid - c * S::Q] : T(0);
   }
   lds_barrier();
@@ -223,8 +227,8 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
             constexpr int q = decltype(qc)::value;
             g[q][0] = fld[(long long)q * p.N + own];
           });
-        } else if (bidx == info.eq_cached[0] || bidx == info.eq_cached[1]) {
-          const int c = bidx == info.eq_cached[0] ? 0 : 1;
+        } else if (bidx == info.eq0 || bidx == info.eq1) {
+          const int c = bidx == info.eq0 ? 0 : 1;
           static_for<S::Q>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             g[q][0] = lds_feq[c][q];

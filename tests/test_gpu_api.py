@@ -459,25 +459,37 @@ def test_cli_convergence_command_with_its_defaults(capsys):
     assert "FAILED" not in capsys.readouterr().out
 
 
-def test_bench_slab_path_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("transport", ["auto", "all"])
+def test_bench_slab_path_on_one_gpu(tmp_path, transport):
     """`bench.py --slab` (the N > 1 code path with the rank exchanging its ghost planes with itself through RCCL) on a
-    small grid: every candidate -- single-step, two-step, two-step with the signalled launch -- ends bit-identical to
-    the single-step reference, one is chosen, and the line carries the fields the driver reads."""
+    small grid.  auto: the single-step driver (timed first, its line held) and the two-step driver with the direct
+    schedule; all: also the edge-launch schedule, the signalled launch and the peer-window transports.  Every candidate
+    that ran ends bit-identical to the single-step reference after the warm-up probe AND after its timed batches, one
+    is chosen, and the line carries the fields the driver reads."""
     import json
     import subprocess
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LT_SLAB_FORCE_P2P="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29200 + os.getpid() % 500))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--slab", "--size", "64", "--steps", "6", "--warmup", "3",
-                          "--batches", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+                          "--batches", "2", "--transport", transport], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
-    transport = line["config"]["transport"]
-    assert set(transport["warmup_ms_per_step"]) == {"single-step/rccl", "two-step/rccl", "two-step/rccl-signalled"}
-    assert all(isinstance(v, float) for v in transport["warmup_ms_per_step"].values()), transport
-    assert transport["checks"] == {"two-step/rccl": "bit-identical to single-step/rccl",
-                                   "two-step/rccl-signalled": "bit-identical to single-step/rccl"}
+    t = line["config"]["transport"]
+    ran = set(t["warmup_ms_per_step"])
+    expected = {"single-step/rccl", "two-step/rccl"}
+    if transport == "all":
+        expected |= {"two-step/rccl-edges", "two-step/rccl-signalled"}
+    assert expected <= ran, t
+    assert all(isinstance(v, float) for v in t["warmup_ms_per_step"].values()), t
+    for name in ran - {"single-step/rccl"}:
+        assert "bit-identical to single-step/rccl after the warm-up probe" in t["checks"][name], t
+        assert "bit-identical after the timed batches too" in t["checks"][name], t
+    # only the peer-window transports may be unavailable on a box (no symmetric memory)
+    assert all(name.split("/")[1].startswith("window") for name in t["failures"]), t
+    assert t["chosen"] in ran
     assert line["n_gpus"] == 1 and line["steps"] == 6 and line["value"] > 0 and line["unit"] == "MLUPS"
+    assert line["repeats_per_batch"] >= 1 and len(line["batches_ms_per_step"]) == 2
 
 
 def test_non_native_mode_on_a_gpu_device():

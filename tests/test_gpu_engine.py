@@ -1077,3 +1077,154 @@ def test_two_step_slab_reads_only_the_exchanged_populations_of_the_ghost_planes(
     out = torch.zeros_like(f)
     plan.stream_collide_twice_planes(g, out, 0.7, 2, n2 - 2)
     assert torch.equal(out[:, 2:n2 - 2], ref[:, 2:n2 - 2])
+
+
+# --------------------------------------------------------------------------- round 3: padded populations
+@pytest.mark.parametrize("name,lat,dt,snaps", TWO_STEP_GOLDEN, ids=[t[0] for t in TWO_STEP_GOLDEN])
+@pytest.mark.parametrize("pad", [-1, 0, 64, 2368])
+def test_resident_populations_reproduce_the_reference_vectors_bit_for_bit(name, lat, dt, snaps, pad):
+    """the fused steps on the ENGINE's padded ping-pong buffers (lt_resident_load / _advance /
+    _store) against the reference's own vectors on grids the two-step kernel takes -- whatever the distance between the
+    populations (engine's choice, dense, 256 B, 9472 B), the caller's dense tensors see the reference's bits, and the
+    steps really went through two-step launches."""
+    g = golden(name)
+    plan = plan_for(lat, TORCH_DT[dt], "bgk", g["f0"].shape[1:])
+    plan.set_two_step(1)
+    plan.set_resident(1, pad)
+    on, stride = plan.resident_enabled()
+    nodes = int(np.prod(g["f0"].shape[1:]))
+    assert on and stride >= nodes and (pad < 0 or stride - nodes in range(pad, pad + 64))
+    f0, out = dev(g["f0"]), torch.empty_like(dev(g["f0"]))
+    done = 0
+    for n in snaps:                                      # carry on from the resident state between the looks
+        if done == 0:
+            plan.resident_load(f0, float(g["tau"]))
+            plan.resident_advance(float(g["tau"]), n - 1)
+        else:
+            plan.resident_advance(float(g["tau"]), n - done)
+        info = plan.last_run_info()
+        fused = n - 1 if done == 0 else n - done
+        assert info["two_step_launches"] == fused // 2 and info["single_step_launches"] == fused % 2, info
+        plan.resident_store(out)
+        np.testing.assert_array_equal(out.cpu().numpy(), g[f"f{n}"])
+        done = n
+    assert torch.equal(f0, dev(g["f0"]))                # the caller's populations were only read
+    plan.resident_free()
+    with pytest.raises(Exception, match="no resident populations"):
+        plan.resident_advance(float(g["tau"]), 1)
+
+
+def test_simulation_on_resident_populations_equals_the_dense_path():
+    """lt.Simulation with the engine-owned buffers switched on (what `automatic` does beyond the caches) against the
+    same steps on the caller's dense tensors: batches, looks in between, in-place edits and re-assignments of flow.f,
+    odd and even counts -- flow.f is the same tensor of bits either way, and stays a plain [q, *res] tensor."""
+    import lettuce_amd as lt
+    c = lt.Context("cuda:0", torch.float32, use_native=True)
+
+    def fresh(resident):
+        flow = lt.TaylorGreenVortex(c, [16, 32, 64], 400, 0.1, lt.D3Q19())
+        sim = lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])
+        sim._native.plan.set_two_step(1)
+        sim._native.plan.set_resident(1 if resident else 0)
+        return flow, sim
+    (fa, sa), (fb, sb) = fresh(True), fresh(False)
+    for k in (4, 3, 3):
+        sa(k); sb(k)
+    assert fa._pending is not None                      # nobody has looked yet
+    assert torch.equal(fa.f, fb.f) and fa.f.is_contiguous() and list(fa.f.shape) == [19, 16, 32, 64]
+    sa(2); sb(2)                                        # carries on from what was shown
+    assert sa._native.plan.last_run_info()["two_step_launches"] == 1
+    assert torch.equal(fa.f, fb.f)
+    fa.f[3] *= 1.01; fb.f[3] *= 1.01                    # in-place edit: the resident state is stale
+    sa(3); sb(3)
+    assert torch.equal(fa.f, fb.f)
+    sa(5)                                               # a pass is pending ...
+    fa.f = fb.f.clone()                                 # ... and dropped by an assignment
+    assert fa._pending is None
+    sa(2); sb(2)
+    assert torch.equal(fa.f, fb.f)
+    assert torch.equal(fa.f_next[0], fa.f_next[0])      # f_next is a plain tensor too
+    rho = fa.rho()
+    assert torch.isfinite(rho).all()
+
+
+@pytest.mark.parametrize("lat,coll,dt", [("D3Q19", "bgk", "f32"), ("D3Q27", "kbc", "f32"), ("D3Q19", "bgk", "f64")])
+def test_slab_kernels_with_a_population_stride_equal_the_dense_ones(lat, coll, dt):
+    """lt_plan_set_population_stride: every slab-layout entry point (collide / stream / fused planes, the two-step
+    launches, pack / unpack, the reductions) on padded tensors against the same calls on dense ones."""
+    from lettuce_amd._native import Plan, LAYOUT_SLAB
+    T = TORCH_DT[dt]
+    res = [64, 16, 12]
+    dense = Plan(lat, T, coll, res, [], layout=LAYOUT_SLAB, ghost_planes=2)
+    padded = Plan(lat, T, coll, res, [], layout=LAYOUT_SLAB, ghost_planes=2)
+    nodes = 64 * 16 * 16
+    padded.set_population_stride(nodes + 64 * (3 if dt == "f32" else 5))
+    torch.manual_seed(5)
+    f = (0.05 + 0.01 * torch.rand(dense.f_shape, device="cuda", dtype=T)).contiguous()
+    fp = padded.populations_like(f)
+    assert not fp.is_contiguous() and torch.equal(fp, f)
+    n2 = f.shape[1]
+    a, ap = torch.zeros_like(f), padded.empty_populations().zero_()
+    for name, args in (("collide_planes", (0.6, 2, n2 - 2)), ("stream_collide_planes", (0.6, 1, n2 - 1))):
+        getattr(dense, name)(f, a, *args)
+        getattr(padded, name)(fp, ap, *args)
+        assert torch.equal(a, ap), name
+    dense.stream_planes(f, a, 1, n2 - 1)
+    padded.stream_planes(fp, ap, 1, n2 - 1)
+    assert torch.equal(a, ap)
+    if coll == "bgk":
+        dense.stream_collide_twice_planes(f, a, 0.6, 2, n2 - 2)
+        padded.stream_collide_twice_planes(fp, ap, 0.6, 2, n2 - 2)
+        assert torch.equal(a, ap)
+        q_msg = dense.two_step_message_blocks()
+        m, mp = torch.zeros([q_msg, 16, 64], device="cuda", dtype=T), torch.zeros([q_msg, 16, 64], device="cuda", dtype=T)
+        dense.pack_two_step(a, -1, m); padded.pack_two_step(ap, -1, mp)
+        assert torch.equal(m, mp)
+        dense.unpack_two_step(a, +1, m); padded.unpack_two_step(ap, +1, mp)
+        assert torch.equal(a, ap)
+    assert float(dense.kinetic_energy_lu(f)) == float(padded.kinetic_energy_lu(fp))
+    assert float(dense.mass(f)) == float(padded.mass(fp))
+    with pytest.raises(Exception, match="population stride"):
+        padded.set_population_stride(nodes + 3)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("edge", [2, 3])
+def test_direct_edge_launch_reads_the_received_messages_and_writes_the_outgoing_ones(dt, edge):
+    """lt_stream_collide_twice_edges_direct: the planes beyond the cuts come from the halo
+    messages as they arrived, the ghost planes of the field hold garbage; its output planes and both outgoing messages
+    are those of the launch that reads unpacked ghost planes followed by the pack kernel -- on padded slab tensors."""
+    from lettuce_amd._native import Plan, LAYOUT_SLAB
+    T = TORCH_DT[dt]
+    nx = 64 if dt == "f32" else 32
+    plan = Plan("D3Q19", T, "bgk", [nx, 16, 12], [], layout=LAYOUT_SLAB, ghost_planes=2)
+    plan.set_population_stride(nx * 16 * 16 + 128)
+    torch.manual_seed(17)
+    f = plan.populations_like(0.05 + 0.01 * torch.rand(plan.f_shape, device="cuda", dtype=T))
+    n2 = f.shape[1]
+    from_below = (0.05 + 0.01 * torch.rand([19, 16, nx], device="cuda", dtype=T)).contiguous()
+    from_above = (0.05 + 0.01 * torch.rand([19, 16, nx], device="cuda", dtype=T)).contiguous()
+    # the classic way: scatter the messages into the ghost planes, launch, gather the outgoing messages
+    g = plan.populations_like(f)
+    plan.unpack_two_step(g, -1, from_below)
+    plan.unpack_two_step(g, +1, from_above)
+    want = plan.empty_populations().zero_()
+    plan.stream_collide_twice_planes(g, want, 0.7, 2, n2 - 2)
+    want_down, want_up = torch.empty_like(from_below), torch.empty_like(from_below)
+    plan.pack_two_step(want, -1, want_down)
+    plan.pack_two_step(want, +1, want_up)
+    # the direct way: ghost planes poisoned
+    f[:, :2] = float("nan"); f[:, n2 - 2:] = float("nan")
+    got = plan.empty_populations().zero_()
+    got_down, got_up = torch.zeros_like(from_below), torch.zeros_like(from_below)
+    plan.stream_collide_twice_edges_direct(f, got, 0.7, edge, from_below, from_above, got_down, got_up)
+    if n2 - 4 > 2 * edge:
+        plan.stream_collide_twice_planes(f, got, 0.7, 2 + edge, n2 - 2 - edge)
+    assert torch.equal(got[:, 2:n2 - 2], want[:, 2:n2 - 2])
+    assert torch.equal(got_down, want_down) and torch.equal(got_up, want_up)
+    # without messages the same entry point reads the ghost planes of the field
+    got2 = plan.empty_populations().zero_()
+    plan.stream_collide_twice_edges_direct(g, got2, 0.7, edge, None, None, got_down.zero_(), got_up.zero_())
+    assert torch.equal(got2[:, 2:2 + edge], want[:, 2:2 + edge]) and torch.equal(got_down, want_down)
+    with pytest.raises(Exception, match="both received messages or"):
+        plan.stream_collide_twice_edges_direct(f, got, 0.7, edge, from_below, None, got_down, got_up)

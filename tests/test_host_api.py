@@ -282,6 +282,56 @@ def test_library_exports_every_declared_symbol(engine_library):
     assert lib.lt_plan_destroy(None) == 0
 
 
+def test_two_step_admission_by_descriptor_knows_the_4_gib_limit(engine_library):
+    """a plan with boundaries whose field reaches 4 GiB must not be put on the two-step path (its
+    kernel addresses the field with 32-bit offsets); the rule lt_run / lt_plan_two_step_admitted apply is a
+    descriptor-only query, checked here without a device: Obstacle D3Q19 fp32 at 384^3 (4.0 GiB) and D3Q27 fp64 at
+    272^3 are refused with masks and fine without, 256^3 is fine either way."""
+    from lettuce_amd import _native
+    lib = _native.load_library()
+    c = _native.ctypes
+
+    def limits(stencil, dtype, shape, masked, layout=0, ghosts=0):
+        d = _native._PlanDesc()
+        d.abi_version, d.stencil, d.dtype, d.collision = 1, _native.STENCIL_IDS[stencil], _native.DTYPE_IDS[dtype], 1
+        d.layout, d.ghost_planes, d.dims = layout, ghosts, len(shape)
+        for a, n in enumerate(shape):
+            d.shape[a] = n
+        w, r, ok = c.c_int32(), c.c_int32(), c.c_int32()
+        assert lib.lt_two_step_limits(c.byref(d), int(masked), c.byref(w), c.byref(r), c.byref(ok)) == 0, lib.lt_last_error()
+        return w.value, r.value, bool(ok.value)
+    assert limits("D3Q19", torch.float32, [256] * 3, True) == (64, 8, True)
+    assert limits("D3Q19", torch.float32, [384] * 3, True) == (64, 8, False)      # 19 * 384^3 * 4 B = 4.01 GiB
+    assert limits("D3Q19", torch.float32, [384] * 3, False) == (64, 8, True)
+    assert limits("D3Q19", torch.float32, [376, 384, 384], True)[2]                # 3.93 GiB
+    assert limits("D3Q27", torch.float32, [256] * 3, True) == (64, 4, True)
+    assert limits("D3Q27", torch.float64, [272] * 3, True)[1:] == (0, False)       # no two-step kernel, and 4.05 GiB
+    assert limits("D3Q19", torch.float64, [256] * 3, False) == (32, 8, True)
+    # the slab layout counts its ghost planes
+    assert limits("D3Q19", torch.float32, [512, 512, 212], True, layout=1, ghosts=2) == (64, 8, False)
+    assert limits("D3Q19", torch.float32, [512, 512, 208], True, layout=1, ghosts=2) == (64, 8, True)
+    assert limits("D2Q9", torch.float32, [4096, 4096], True) == (512, 1, True)
+    bad = _native._PlanDesc()
+    bad.abi_version, bad.stencil, bad.dims = 1, 1, 2
+    assert lib.lt_two_step_limits(c.byref(bad), 0, None, None, None) == 1 and b"3-dimensional" in lib.lt_last_error()
+
+
+def test_every_plan_method_that_launches_runs_on_the_plans_device():
+    """a Plan method that hands torch's CURRENT stream to the engine must make the plan's GPU the
+    current device first (``_on_device``), or a plan on cuda:1 launches on cuda:0's stream with cuda:1's pointers."""
+    import inspect
+    from lettuce_amd import _native
+    missing = []
+    for name, fn in vars(_native.Plan).items():
+        if not callable(fn) or name.startswith("__"):
+            continue
+        src = inspect.getsource(inspect.unwrap(fn))
+        if "_stream_handle()" in src or "torch.cuda.current_stream()" in src or ".record()" in src:
+            if not hasattr(fn, "__wrapped__"):
+                missing.append(name)
+    assert missing == [], missing
+
+
 def test_native_context_never_falls_back(monkeypatch, engine_library):
     """use_native with no engine library must raise, not run torch ops."""
     from lettuce_amd import _native
