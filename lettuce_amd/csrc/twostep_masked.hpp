@@ -203,8 +203,12 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int nbr_lane = (lane - info.abb_side) & 63;                    // AX = 0: who holds the node next to mine
 
+  // The plane index is uniform, but hipcc does not always see it (in the D3Q27 instantiations it kept it in a vector
+  // register, multiplied it there and wrapped every buffer access of a plane -- whose plane offset is the SCALAR
+  // operand -- in a read-first-lane loop: 27 loops per phase).  Saying so keeps plane arithmetic on the scalar unit.
+  auto uniform = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
   auto wrapped = [&](int plane) __attribute__((always_inline)) {
-    return p.wrap2 ? (plane < 0 ? plane + p.n2 : (plane >= p.n2 ? plane - p.n2 : plane)) : plane;
+    return uniform(p.wrap2 ? (plane < 0 ? plane + p.n2 : (plane >= p.n2 ? plane - p.n2 : plane)) : plane);
   };
 
   // collision, then the boundaries in index order, on the post-streaming populations g of the node `own`
@@ -263,15 +267,17 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   T sa_rho = T(1), sa_j[3] = {T(0), T(0), T(0)};      // phase A: moments of this column one plane earlier
   auto load_a = [&](int plane) __attribute__((always_inline)) {
     const int g2 = wrapped(plane);
-    int g2m = plane - 1, g2p = plane + 1;
+    int g2m = uniform(plane - 1), g2p = uniform(plane + 1);
     if (p.wrap2) {
       g2m = g2 == 0 ? p.n2 - 1 : g2 - 1;
       g2p = g2 == p.n2 - 1 ? 0 : g2 + 1;
     }
-    const unsigned off0 = (unsigned)g2 * plane_bytes, offm = (unsigned)g2m * plane_bytes;
+    // (the products too: hipcc sometimes forms them on the vector unit, and a vector soffset means a loop per load)
+    const unsigned off0 = (unsigned)uniform((int)((unsigned)g2 * plane_bytes)),
+                   offm = (unsigned)uniform((int)((unsigned)g2m * plane_bytes));
     // at an a2 outlet plane the downward populations are not streamed: they come from the node itself
     const bool keep_down = abb_a2 && g2 == info.abb_plane;
-    const unsigned offp = (unsigned)(keep_down ? g2 : g2p) * plane_bytes;
+    const unsigned offp = (unsigned)uniform((int)((unsigned)(keep_down ? g2 : g2p) * plane_bytes));
     if (in_a) {
       nd_pre = p.node[(unsigned)g2 * plane_nodes + a_own];
       static_for<S::Q>([&](auto qc) {
@@ -292,7 +298,8 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
     }
   };
   // r = index of the plane relative to s - 1; r3 = r % 3; plane = its a2 index
-  auto compute_a = [&](int r, int r3, int plane) __attribute__((always_inline)) {
+  auto compute_a = [&](int r_, int r3_, int plane) __attribute__((always_inline)) {
+    const int r = uniform(r_), r3 = uniform(r3_);
     if (in_a) {
       const int g2 = wrapped(plane);
       const unsigned own = (unsigned)g2 * plane_nodes + a_own;
@@ -324,7 +331,8 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   // post-streaming populations of the output node of plane k2 (relative index r) from the intermediate state:
   // upward populations from plane r - 1, in-plane ones from r, downward ones from r + 1 -- or, at the
   // outlet plane, from the node itself
-  auto read_b = [&](int r, int r3, int k2) __attribute__((always_inline)) {
+  auto read_b = [&](int r_, int r3_, int k2_) __attribute__((always_inline)) {
+    const int r = uniform(r_), r3 = uniform(r3_), k2 = uniform(k2_);
     const bool keep_down = abb_a2 && k2 == info.abb_plane;
     const int dslot = keep_down ? r3 : (r3 == 2 ? 0 : r3 + 1);
     static_for<S::Q>([&](auto qc) {
@@ -344,7 +352,8 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
       }
     });
   };
-  auto finish_b = [&](int k2) __attribute__((always_inline)) {
+  auto finish_b = [&](int k2_) __attribute__((always_inline)) {
+    const int k2 = uniform(k2_);
     const unsigned own = (unsigned)k2 * plane_nodes + b_own;
     T keep_rho = T(1), keep_j[3] = {T(0), T(0), T(0)};
     if constexpr (AX == 0) {
@@ -358,7 +367,7 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
       collide_and_bound(f, nd_b, abb_a2 && k2 == info.abb_plane, own, sb_rho, sb_j);
       sb_rho = keep_rho; sb_j[0] = keep_j[0]; sb_j[1] = keep_j[1]; sb_j[2] = keep_j[2];
     }
-    const unsigned off = (unsigned)k2 * plane_bytes;
+    const unsigned off = (unsigned)uniform((int)((unsigned)k2 * plane_bytes));
     static_for<S::Q>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       BufIO<T>::store_nt(f[q][0], out_r, out_off[q], off);
