@@ -421,6 +421,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed = world > 1 or args.slab
+    if args.slab and world == 1:
+        # the rehearsal is only worth something if the halo messages really travel through RCCL (to the rank itself)
+        os.environ.setdefault("LT_SLAB_FORCE_P2P", "1")
     if args.workload != "cfg3" and not distributed:
         raise SystemExit("--workload cfg5 is a slab workload: use --gpus N (N = 4 is BASELINE's configs[4]) or --slab")
     if distributed:
@@ -806,7 +809,9 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
             t0 = time.perf_counter()
             cand(args.steps)                    # sizes the batches (untimed)
             barrier()
-            repeat = repeats_for(max_over_ranks(time.perf_counter() - t0))
+            # later candidates repeat as often as the first one did: the same number of steps, so that the populations
+            # after the timed batches can be compared too
+            repeat = reference.get("repeat") or repeats_for(max_over_ranks(time.perf_counter() - t0))
             batch_s, err = [], None
             for _ in range(max(1, args.batches)):
                 barrier()
