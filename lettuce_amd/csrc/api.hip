@@ -636,6 +636,10 @@ bool two_step_wanted(lt_plan *p) {
   if (p->two_step == 0 || p->desc.ghost_planes) return false;
   if (!two_step_possible(p, nullptr)) return false;
   if (p->two_step == 1) return true;
+  // KBC inside the masked two-step kernel agrees with the one-step kernel at rounding level only (hipcc contracts
+  // its multiply-adds differently in the two inlining contexts): never automatic, so that the result of n steps
+  // does not depend on how the caller splits them into batches
+  if (p->desc.collision == LT_COLLISION_KBC) return false;
   const long long bytes = 2ll * p->unit.q * p->N * p->esize;
   return bytes > (128ll << 20);
 }

@@ -118,8 +118,15 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   constexpr int T0 = B::T0, H0 = B::H0, NI = B::NI, NO = B::NO;
   constexpr int NU = B::template count<LAYOUT, 1>(), NC = B::template count<LAYOUT, 0>(),
                 ND = B::template count<LAYOUT, -1>();
-  static_assert(COLL == 0 || COLL == 1, "two-step kernel: streaming only or BGK");
+  static_assert(COLL == 0 || COLL == 1 || COLL == 2, "two-step kernel: streaming only, BGK or (experiment) KBC");
   static_assert(NO % 64 == 0, "the output nodes of a tile fill whole waves");
+  // D3Q27: the collision + boundary code of one node is ~3000 instructions, and the sweep below inlines it fifteen
+  // times (three prologue planes, a peeled, a steady-state and a tail copy of the interval, for two wave roles):
+  // 300 KB of code against a 64 KB instruction cache shared by two compute units.  COMPACT keeps one copy of the
+  // prologue plane and one of the interval per role (the conditions of the tail are then tested in every interval):
+  // 105 KB -- and measured SLOWER (Obstacle D3Q27 256^3 BGK: 0.520 against 0.49 ms per update on the same box), so
+  // the instruction cache is not what holds this kernel back; kept as a switch for the record.
+  constexpr bool COMPACT = false;
   __shared__ T lds_u[4][NU][NI];
   __shared__ T lds_c[3][NC][NI];
   __shared__ T lds_d[3][ND][NI];
@@ -218,6 +225,7 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
     const int bidx = nd & 0x7f;
     if (bidx == 0) {
       if constexpr (COLL == 1) collide_bgk<T, S, LAYOUT, 1, 0>(g, p.tau_inv);
+      if constexpr (COLL == 2) collide_kbc<T, S, LAYOUT, 1, 0>(g, p.beta, p.inv_beta);
     }
     if (on_outlet && (bidx == 0 || info.abb_slot <= bidx)) abb_apply_ax<T, S, LAYOUT, AX>(info.abb_side, rn, jn, g);
     if (bidx != 0) {
@@ -386,9 +394,14 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
       load_a(s - 2);
       if (in_a) moments_for_outlet(pre, nd_pre, (unsigned)wrapped(s - 2) * plane_nodes + a_own, sa_rho, sa_j);
     }
-    load_a(s - 1); compute_a(0, 0, s - 1);
-    load_a(s);     compute_a(1, 1, s);
-    load_a(s + 1); compute_a(2, 2, s + 1);
+    if constexpr (COMPACT) {
+#pragma clang loop unroll(disable)
+      for (int i = 0; i < 3; ++i) { load_a(s - 1 + i); compute_a(i, i, s - 1 + i); }
+    } else {
+      load_a(s - 1); compute_a(0, 0, s - 1);
+      load_a(s);     compute_a(1, 1, s);
+      load_a(s + 1); compute_a(2, 2, s + 1);
+    }
     if constexpr (HAS_B) nd_b_next = p.node[(unsigned)s * plane_nodes + b_own];
     if (s + 2 <= last) load_a(s + 2);
     int r = 1, r3 = 1;                              // output plane k has relative index k - s + 1
@@ -413,10 +426,13 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
       r3 = r3 == 2 ? 0 : r3 + 1;
     };
     int k = s;
-    if (last - s >= 4) {
-      interval(std::true_type{}, k++);              // peeled: see the header of this file
-      for (; k + 3 <= last; ++k) interval(std::true_type{}, k);
+    if constexpr (!COMPACT) {
+      if (last - s >= 4) {
+        interval(std::true_type{}, k++);            // peeled: see the header of this file
+        for (; k + 3 <= last; ++k) interval(std::true_type{}, k);
+      }
     }
+#pragma clang loop unroll(disable)
     for (; k < last; ++k) interval(std::false_type{}, k);
   };
 
