@@ -352,10 +352,13 @@ int lt_stream_collide_twice(lt_plan *plan, const void *f_dev, void *out_dev, dou
  * calls.  2-D lattices, extents multiples of 8; plans with masks too (bounce-back, equilibrium and at most
  * one anti-bounce-back outlet, for which one more ring of nodes is recomputed: n_steps <= 7);
  * LT_ERR_UNSUPPORTED otherwise.
- * lt_plan_set_many_step: lt_run / lt_continue use it for their fused steps: -1 = automatic (grids up
- * to 256 x 256 nodes, with masks up to 256 x 128; BGK / no collision, where it is bit-identical to the
- * one-step kernel),
- * 0 = never, 1 = whenever supported. */
+ * Small 3-D grids: n_steps = 2 exactly (the 10^3 neighbourhood of an 8^3 tile in LDS): periodic plans in the
+ * reference layout without masks, extents multiples of 8, BGK / no collision, every 3-D lattice and dtype whose
+ * q x 1000 values fit the LDS (not D3Q27 fp64); bit-identical to two lt_stream_collide calls.
+ * lt_plan_set_many_step: lt_run / lt_continue use it for their fused steps: -1 = automatic (2-D grids up
+ * to 256 x 256 nodes, with masks up to 256 x 128; BGK / no collision, where it is bit-identical to the one-step
+ * kernel; never for 3-D grids, where two steps per launch measured slower than two launches), 0 = never,
+ * 1 = whenever supported. */
 int lt_stream_collide_many(lt_plan *plan, const void *f_dev, void *out_dev, double tau, int32_t n_steps,
                            void *stream);
 int lt_plan_set_many_step(lt_plan *plan, int32_t mode);

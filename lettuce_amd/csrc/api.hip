@@ -645,17 +645,19 @@ bool two_step_wanted(lt_plan *p) {
 }
 
 constexpr int kManyMax = 8;        // == kManyMax of unit.inc
-// steps per many-step launch: a plan with an outlet recomputes one more ring of nodes around each tile
-int many_max(const lt_plan *p) { return kManyMax - ((p->masked && p->n_abb > 0) ? 1 : 0); }
+// steps per many-step launch: a plan with an outlet recomputes one more ring of nodes around each tile; the 3-D
+// kernel does two (its neighbourhood of an 8^3 tile is 10^3 nodes: q x 1000 values of LDS)
+int many_max(const lt_plan *p) { return p->unit.d == 3 ? 2 : kManyMax - ((p->masked && p->n_abb > 0) ? 1 : 0); }
 
 // Several steps per launch (lbm_many_kernel): 2-D, tiles of 8 x 8, with masks at most one outlet.  Every
 // workgroup recomputes a halo of K - 1 nodes around its tile (K with an outlet), so this only pays while the
 // grid is launch-bound; "automatic" stops at 256 x 256 nodes, 256 x 128 with masks (measured,
 // tools/small_grid_bench.py, tools/small_masked_bench.py).
 bool many_step_wanted(lt_plan *p) {
-  if (p->many == 0 || p->desc.ghost_planes || p->unit.d != 2) return false;
-  if (p->masked && p->n_abb > 1) return false;
-  if (p->n0 % 8 != 0 || p->n1 % 8 != 0) return false;
+  if (p->many == 0 || p->desc.ghost_planes || p->unit.d < 2) return false;
+  if (p->masked && (p->n_abb > 1 || p->unit.d == 3)) return false;
+  if (p->n0 % 8 != 0 || p->n1 % 8 != 0 || (p->unit.d == 3 && p->n2 % 8 != 0)) return false;
+  if (p->unit.d == 3 && p->desc.layout != LT_LAYOUT_REFERENCE) return false;
   lt::StepArgs a;
   memset(&a, 0, sizeof a);
   a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = lt::kFusedMany;
@@ -670,6 +672,13 @@ bool many_step_wanted(lt_plan *p) {
   // recomputes a wider ring: 128 x 64 nodes 4.2 -> 2.4 us per step, 128 x 128 4.3 -> 2.5, 256 x 128 4.5 -> 3.3,
   // 256 x 256 5.6 -> 5.7 (tools/small_masked_bench.py, fp64)
   if (p->masked) return p->N <= 256ll * 128ll;
+  // 3-D (lbm_many3d_kernel, two steps per launch): never automatic.  Measured slower than one launch per step on
+  // every grid (tools/small_grid_bench.py, D3Q19 fp32, us per step: 16^3 3.66 -> 4.29, 32^3 4.21 -> 5.79, 48^3 6.5 ->
+  // 7.9, 64^3 8.3 -> 15.4): two steps amortise one launch gap (~2 us) but the launch is a chain of two dependent
+  // gather -> collide phases with a barrier in between, on 1000-thread workgroups that gather 10-node rows; the 2-D
+  // kernel wins because it amortises EIGHT steps per launch, which the LDS does not allow in 3-D (K = 3 needs the
+  // 12^3 neighbourhood: 131 KB for D3Q19 fp32 and 3.4 x the arithmetic).
+  if (p->unit.d == 3) return false;
   return p->N <= 256ll * 256ll;
 }
 
@@ -688,17 +697,21 @@ int fused_section(lt_plan *p, void *&cur, void *&other, double tau, long long fu
   p->last_many = 0;
   if (many_step_wanted(p) && fused >= 2) {
     // launches of up to kManyMax steps each; the events bracket them
+    long long odd = 0;
     if (p->ev_start) (void)hipEventRecord(p->ev_start, hs);
     while (fused > 0) {
       p->many_now = fused < many_max(p) ? (int)fused : many_max(p);
-      rc = step(p, lt::kFusedMany, cur, other, tau, 0, p->n2, stream);
+      // the 3-D kernel does exactly two steps: an odd one at the end is an ordinary launch
+      const int mode = (p->unit.d == 3 && p->many_now == 1) ? lt::kFused : lt::kFusedMany;
+      rc = step(p, mode, cur, other, tau, 0, p->n2, stream);
       if (rc) return rc;
       void *t = cur; cur = other; other = t;
       fused -= p->many_now;
-      ++p->last_many;
+      if (mode == lt::kFusedMany) ++p->last_many; else ++odd;
     }
     if (p->ev_stop) (void)hipEventRecord(p->ev_stop, hs);
-    p->last_twice = p->last_single = 0;
+    p->last_twice = 0;
+    p->last_single = odd;
     return LT_OK;
   }
   const long long twice = two_step_wanted(p) ? fused / 2 : 0;

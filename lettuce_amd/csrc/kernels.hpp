@@ -1386,6 +1386,63 @@ lbm_many_kernel(const KParams<T> p, const int K) {
   }
 }
 
+// ---- two steps per launch on small 3-D grids -----------------------------------------------------
+// The 3-D counterpart of lbm_many_kernel for grids that are bound by launch latency (32^3: 3.9 us per step for
+// well under 1 us of work).  A workgroup of 1000 threads loads the 10^3 neighbourhood of its 8^3 tile (one node per
+// thread: the ordinary pull from global memory + collide), leaves the populations in LDS (q x 1000 values: 76 KB
+// for D3Q19 fp32, two workgroups per CU), and the 512 threads of the inner tile pull their second step from there,
+// collide and store.  The shell is recomputed by every workgroup that needs it (1.95 x the arithmetic of the first
+// step) -- free while the chip waits for launches.  Same pull, same collide as the one-step kernel: two launches of
+// lbm_kernel give the same bits (BGK / streaming); grids smaller than the neighbourhood wrap (8^3).
+constexpr int kMany3dTile = 8, kMany3dEdge = kMany3dTile + 2, kMany3dNodes = kMany3dEdge * kMany3dEdge * kMany3dEdge;
+template <typename T, class S, int COLL>
+__global__ void __launch_bounds__(1024) lbm_many3d_kernel(const KParams<T> p) {
+  static_assert(S::D == 3, "3-D lattices");
+  using M = MemMap<S, 0>;
+  constexpr int E = kMany3dEdge, NR = kMany3dNodes, TO = kMany3dTile;
+  __shared__ T lds[S::Q][NR];
+  const int tid = threadIdx.x;
+  const int tiles0 = p.n0 / TO, tiles1 = p.n1 / TO;
+  int b = blockIdx.x;
+  const int t0 = (b % tiles0) * TO; b /= tiles0;
+  const int t1 = (b % tiles1) * TO; b /= tiles1;
+  const int t2 = b * TO;
+  const bool in_region = tid < NR;
+  const int i2 = tid / (E * E), i1 = (tid / E) % E, i0 = tid % E;
+  auto wrap = [](int x, int n) { x %= n; return x < 0 ? x + n : x; };
+  const int g0 = wrap(t0 - 1 + i0, p.n0), g1 = wrap(t1 - 1 + i1, p.n1), g2 = wrap(t2 - 1 + i2, p.n2);
+  T f[S::Q][1];
+  if (in_region) {
+    static_for<S::Q>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1), e2 = M::e(q, 2);
+      const int s0 = e0 == 0 ? g0 : wrap(g0 - e0, p.n0), s1 = e1 == 0 ? g1 : wrap(g1 - e1, p.n1),
+                s2 = e2 == 0 ? g2 : wrap(g2 - e2, p.n2);
+      f[q][0] = p.in[(long long)q * p.Ni + ((long long)s2 * p.n1 + s1) * p.n0 + s0];
+    });
+    if constexpr (COLL == 1) collide_bgk<T, S, 0, 1, 0>(f, p.tau_inv);
+    static_for<S::Q>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      lds[q][tid] = f[q][0];
+    });
+  }
+  __syncthreads();
+  // second step: the nodes of the tile (distance >= 1 from the border of the neighbourhood)
+  if (in_region && i0 >= 1 && i0 <= TO && i1 >= 1 && i1 <= TO && i2 >= 1 && i2 <= TO) {
+    static_for<S::Q>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1), e2 = M::e(q, 2);
+      f[q][0] = lds[q][tid - (e2 * E + e1) * E - e0];
+    });
+    if constexpr (COLL == 1) collide_bgk<T, S, 0, 1, 0>(f, p.tau_inv);
+    const long long own = ((long long)g2 * p.n1 + g1) * p.n0 + g0;
+    static_for<S::Q>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      p.out[(long long)q * p.No + own] = f[q][0];
+    });
+  }
+}
+
 // ---- auxiliary kernels --------------------------------------------------------------------
 // rho [N], u [d][N] (logical axis order) from f  -- Flow.rho / Flow.u
 template <typename T, class S, int LAYOUT>

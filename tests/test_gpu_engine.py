@@ -1228,3 +1228,45 @@ def test_direct_edge_launch_reads_the_received_messages_and_writes_the_outgoing_
     assert torch.equal(got2[:, 2:2 + edge], want[:, 2:2 + edge]) and torch.equal(got_down, want_down)
     with pytest.raises(Exception, match="both received messages or"):
         plan.stream_collide_twice_edges_direct(f, got, 0.7, edge, from_below, None, got_down, got_up)
+
+
+# --------------------------------------------------------------------------- round 3: two steps per launch, small 3-D grids
+@pytest.mark.parametrize("lat,dt", [("D3Q19", "f32"), ("D3Q19", "f64"), ("D3Q27", "f32"), ("D3Q15", "f32"), ("D3Q15", "f64")])
+@pytest.mark.parametrize("res", [[8, 8, 8], [16, 8, 24], [32, 32, 32], [40, 16, 8]])
+@pytest.mark.parametrize("coll", ["bgk", "none"])
+def test_two_steps_per_launch_on_small_3d_grids_equal_single_steps(lat, dt, res, coll):
+    """lbm_many3d_kernel: the 10^3 neighbourhood of an 8^3 tile in LDS, two stream-collide steps
+    per launch: bit for bit two launches of the one-step kernel, incl. grids smaller than the neighbourhood (8^3:
+    every neighbour is a periodic image of the tile itself) and ragged tile counts."""
+    T = TORCH_DT[dt]
+    L = orc.LATTICES[lat]
+    plan = plan_for(lat, T, coll, res)
+    torch.manual_seed(7)
+    w = torch.rand(L.q, 1, 1, 1, device="cuda", dtype=T) * 0.03 + 0.02
+    f = (w * (1 + 0.05 * torch.rand([L.q] + res, device="cuda", dtype=T))).contiguous()
+    a, b, c = torch.empty_like(f), torch.empty_like(f), torch.empty_like(f)
+    plan.stream_collide(f, a, 0.7)
+    plan.stream_collide(a, b, 0.7)
+    plan.stream_collide_many(f, c, 0.7, 2)
+    assert torch.equal(b, c)
+    with pytest.raises(Exception, match="no kernel|n_steps"):
+        plan.stream_collide_many(f, c, 0.7, 3)
+
+
+@pytest.mark.parametrize("name,dt,n", [("tgv3d_d3q19_bgk_32_f32", "f32", 10), ("tgv3d_d3q19_bgk_16_f64", "f64", 100)])
+def test_small_3d_grids_run_two_steps_per_launch_and_reproduce_the_reference(name, dt, n):
+    """lt_run on a launch-bound 3-D grid with lt_plan_set_many_step(plan, 1) pairs its fused steps into
+    lbm_many3d_kernel launches and returns the reference's populations bit for bit (periodic BGK), for odd and even
+    step counts.  (Not automatic: measured slower than one launch per step, api.hip many_step_wanted.)"""
+    g = golden(name)
+    plan = plan_for("D3Q19", TORCH_DT[dt], "bgk", g["f0"].shape[1:])
+    assert "lbm_many3d_kernel" not in plan.kernel_name()
+    plan.set_many_step(1)
+    assert "lbm_many3d_kernel" in plan.kernel_name()
+    np.testing.assert_array_equal(run_engine(plan, g["f0"], float(g["tau"]), n), g[f"f{n}"])
+    info = plan.last_run_info()
+    assert info["many_step_launches"] == (n - 1) // 2 and info["single_step_launches"] == (n - 1) % 2 and info["two_step_launches"] == 0, info
+    np.testing.assert_array_equal(run_engine(plan, g["f0"], float(g["tau"]), n - 1 if f"f{n - 1}" in g else n), g[f"f{n - 1}"] if f"f{n - 1}" in g else g[f"f{n}"])
+    plan.set_many_step(0)
+    assert "lbm_many3d_kernel" not in plan.kernel_name()
+    np.testing.assert_array_equal(run_engine(plan, g["f0"], float(g["tau"]), n), g[f"f{n}"])
