@@ -333,9 +333,12 @@ def other_configs(lt, device):
     flow.f = start
     sim(3)
     same = bool(torch.equal(flow.f, a))
+    diff, scale = float((flow.f - a).abs().max()), float(a.abs().max())
     r["check"] = {"what": "3 steps of lt.Simulation (fused stream-collide launches) against collide, stream through "
-                          "the operator entry points, torch.equal",
-                  "bit_identical": same, "max_abs_diff": float((flow.f - a).abs().max()),
+                          "the operator entry points; KBC is compared at rounding level (hipcc contracts its "
+                          "multiply-adds differently in the fused and the collide-only kernel; BGK flows are bit-identical)",
+                  "bit_identical": same, "max_abs_diff": diff,
+                  "agrees_at_fp32_rounding_level": diff <= 4e-6 * scale,
                   "finite": bool(torch.isfinite(flow.f).all())}
     rows.append(r)
     del sim, flow, plan, start, a, b, x, y, z

@@ -388,7 +388,7 @@ def test_bench_finds_the_committed_pmc_traffic_for_the_fused_kernel(monkeypatch)
     spec.loader.exec_module(bench)
     with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
         table = json.load(fh)
-    name = "lbm2_kernel<float, lt::d3q19, 0, 1, 64, 8, 1, false, 1>"
+    name = "lbm2_kernel<float, lt::d3q19, 0, 1, 64, 8, 1, 0, 1>"
     # a table from other kernel sources is not used
     monkeypatch.setattr(bench, "source_hash", lambda: "not-the-hash-of-the-table")
     assert bench.traffic_from_profile(name) is None
@@ -401,6 +401,13 @@ def test_bench_finds_the_committed_pmc_traffic_for_the_fused_kernel(monkeypatch)
     # names that gained trailing template parameters since the profile was taken still match
     assert bench.traffic_from_profile(name.replace(", 1>", ", 1, 0>")) == traffic
     assert bench.traffic_from_profile("lbm_kernel<float, lt::d3q19, 0, 1, true, true, false, 1, 0, 0, false>") is None
+    # round 3: the other BASELINE workloads have rows of their own (bench.py's other_configs)
+    kbc = bench.traffic_from_profile("lbm_kernel_occ4<float, lt::d3q27, 0, 2, true, true, true, 1, 0, 3, false>",
+                                     "obstacle3d_d3q27_kbc_f32_256")
+    assert kbc is not None and 0.95 < kbc / (217 * 256 ** 3) < 1.1              # one pass: 217 B per node
+    fp64 = bench.traffic_from_profile("lbm2_kernel<double, lt::d3q19, 0, 1, 32, 8, 1, 0, 1>", "shear3d_d3q19_bgk_f64_384x384x96")
+    assert fp64 is not None and 0.5 < fp64 / (2 * 304 * 384 * 384 * 96) < 0.6
+    assert bench.traffic_from_profile(name, "obstacle3d_d3q27_kbc_f32_256") is None
 
 
 def test_only_reporters_that_opt_in_are_batched():
