@@ -25,7 +25,7 @@ echo "== rocprofv3 kernel trace of the slab rehearsal"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_slab -- python3 $GRAFT_REPO_ROOT/bench.py --slab --steps 100 --batches 2 --driver two-step > $OUT/trace_slab_bench.json 2> $OUT/trace_slab.err; echo "slab trace exit $?"
 for W in cfg2 cfg4 cfg4bgk obst19 cfg5; do
   echo "== $W: kernel trace"
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/w_$W/trace -- python3 $GRAFT_REPO_ROOT/tools/profile_workload.py $W 60 > $OUT/w_$W.json 2> $OUT/w_$W.err; echo "rc $?"
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/w_$W/trace -- python3 $GRAFT_REPO_ROOT/tools/profile_workload.py $W 200 > $OUT/w_$W.json 2> $OUT/w_$W.err; echo "rc $?"
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/w_$W/pmc_$C -- python3 $GRAFT_REPO_ROOT/tools/profile_workload.py $W 24 > /dev/null 2>> $OUT/w_$W.err; echo "pmc $W $C rc $?"
   done
@@ -38,3 +38,6 @@ timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT
 done
 cd $GRAFT_REPO_ROOT
 du -sh $OUT
+echo "== small grids" && timeout -k 10 300 python tools/small_grid_bench.py > $OUT/small_grids.jsonl 2> $OUT/small_grids.err; echo "rc $?"
+echo "== cfg4 with KBC in the two-step kernel" && timeout -k 10 300 python tools/kbc_two_step_probe.py > $OUT/kbc_two_step.jsonl 2> $OUT/kbc_two_step.err; echo "rc $?"
+echo "== other configs" && timeout -k 10 300 python tools/bench_configs.py cfg1 cfg4 cfg4bgk cfg4bgk1 obst19 obst19_1 cfg5 > $OUT/other_configs.jsonl 2> $OUT/other_configs.err; echo "rc $?"
