@@ -421,13 +421,6 @@ int halo2(lt_plan *p, bool do_pack, void *f, int side, void *buf, void *stream) 
 // Returns the memory axis of the outlet (2 without one), or -1: not admitted.
 int masked_two_step_axis(const lt_plan *p) {
   if (!p->nsm_confined) return -1;
-  // D3Q27 in the SLAB layout is not admitted: round 3 found lbm2m_kernel<float, D3Q27, slab, BGK, 64 x 4, AX = 0>
-  // (the Obstacle on z-slabs) returning wrong populations on the inlet's neighbour column in the first output
-  // plane of every segment -- with BGK only, streaming alone is exact, the same source built in round 2 was right,
-  // and three differently compiled variants of round 3 are wrong in the same nodes with different values (DESIGN.md
-  // section 6): an uninitialised read or a miscompilation of that 300 KB kernel that has not been found.  The
-  // one-exchange-per-step driver is the faster one for D3Q27 slabs anyway (0.83 against 0.97 ms per step).
-  if (p->desc.layout == LT_LAYOUT_SLAB && p->unit.q == 27) return -1;
   const int sweep = p->unit.d == 2 ? 1 : 2;          // the slowest memory axis
   if (p->unit.d < 2) return -1;
   int n_abb = 0, axis = 2;
@@ -609,12 +602,9 @@ bool two_step_possible(lt_plan *p, const char **why) {
     return false;
   }
   if (p->masked && (!masked_two_step_ok(p) || (p->desc.ghost_planes && p->n_abb > 0 && masked_two_step_axis(p) != 0))) {
-    *why = (p->desc.layout == LT_LAYOUT_SLAB && p->unit.q == 27)
-               ? "boundaries on a D3Q27 slab: the two-step kernel is not admitted there (use the one-exchange-per-step "
-                 "slab driver)"
-               : "boundaries: at most one anti-bounce-back outlet, at the last plane of the slowest memory axis (periodic "
-                 "plans only) or at an end of the contiguous axis opposite a face of equilibrium nodes; no-streaming bits "
-                 "exactly that outlet's";
+    *why = "boundaries: at most one anti-bounce-back outlet, at the last plane of the slowest memory axis (periodic "
+           "plans only) or at an end of the contiguous axis opposite a face of equilibrium nodes; no-streaming bits "
+           "exactly that outlet's";
     return false;
   }
   lt::StepArgs a;

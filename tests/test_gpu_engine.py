@@ -1270,3 +1270,29 @@ def test_small_3d_grids_run_two_steps_per_launch_and_reproduce_the_reference(nam
     plan.set_many_step(0)
     assert "lbm_many3d_kernel" not in plan.kernel_name()
     np.testing.assert_array_equal(run_engine(plan, g["f0"], float(g["tau"]), n), g[f"f{n}"])
+
+
+@pytest.mark.parametrize("name,lat,dt,snaps", MASKED_GOLDEN[:2], ids=[t[0] for t in MASKED_GOLDEN[:2]])
+@pytest.mark.parametrize("pad", [-1, 192])
+def test_masked_two_step_on_resident_populations_equals_the_dense_path(name, lat, dt, snaps, pad):
+    """Large Obstacle flows run their fused steps as masked two-step launches on the engine's padded buffers
+    (automatic beyond the caches): forced on here on the reference's Obstacle vectors -- boundary tables, masks and
+    per-node bytes stay dense while the populations are padded -- the caller's tensors must see exactly what lt_run
+    gives on dense buffers, and the reference's populations at the outlet's rounding level."""
+    g = golden(name)
+    plan = obstacle_plan(g, lat, "bgk", dt)
+    plan.set_many_step(0)
+    plan.set_two_step(1)
+    tau = float(g["tau"])
+    f0, out = dev(g["f0"]), torch.empty_like(dev(g["f0"]))
+    for n in snaps:
+        plan.set_resident(0)
+        dense = run_engine(plan, g["f0"], tau, n)
+        plan.set_resident(1, pad)
+        assert plan.resident_enabled()[0]
+        plan.resident_load(f0, tau)
+        plan.resident_advance(tau, n - 1)
+        assert plan.last_run_info()["two_step_launches"] == (n - 1) // 2
+        plan.resident_store(out)
+        np.testing.assert_array_equal(out.cpu().numpy(), dense)
+        assert_close(dense, g[f"f{n}"], dt)
