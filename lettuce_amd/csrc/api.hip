@@ -96,6 +96,7 @@ struct lt_plan {
   double *partial = nullptr;
   int masked = 0;
   int n_abb = 0;             // anti-bounce-back outlets of the plan
+  int abb_depth = 0;         // how deep an outlet's neighbour must be rebuilt (lt_plan_create)
   int nsm_confined = 1;      // the no-streaming bits are exactly those of the plan's outlet (lt_plan_set_masks)
   int inlet_faces_outlet = 1;  // outlet along a0: every node of the opposite face is an equilibrium node
   unsigned *mask_flag = nullptr;   // device word written by the mask compilation
@@ -182,9 +183,6 @@ int check_boundary(const lt_plan *p, const lt_boundary_desc &b, int n_abb_before
         return fail(LT_ERR_INVALID, "anti-bounce-back outlet needs >= 2 planes along its axis");
       if (p->desc.ghost_planes && b.axis == 2 && !(b.flags & LT_BOUNDARY_ABSENT) && p->desc.shape[2] < 2)
         return fail(LT_ERR_INVALID, "an outlet along the decomposed (z) axis needs >= 2 planes on its rank");
-      if (n_abb_before > 1)
-        return fail(LT_ERR_UNSUPPORTED,
-                    "more than two AntiBounceBackOutlets per flow are not supported by the HIP engine");
       return LT_OK;
     }
     default:
@@ -483,7 +481,7 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.node = p->node; a.nsm_bits = p->nsm_bits; a.bt = p->bt; a.nb = p->desc.n_boundaries;
   a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = mode;
   a.masked = p->masked;
-  a.abb_depth = p->n_abb > 1 ? p->n_abb - 1 : 0;
+  a.abb_depth = p->abb_depth;
   a.abb_axis = p->masked ? masked_two_step_axis(p) : 2;
   a.n_abb = p->masked ? p->n_abb : 0;
   a.abb0_slot = 0;
@@ -842,6 +840,24 @@ int lt_plan_create(const lt_plan_desc *d, lt_plan **out) {
     if (d->boundaries[i].kind == LT_BOUNDARY_ABB_OUTLET) ++n_abb;
   }
   p->n_abb = n_abb;
+  // How deep the kernels must rebuild an outlet's neighbour (neighbour_moments, DEPTH): where the planes of outlets
+  // meet, an outlet's neighbour node has been rewritten by the outlets with a lower index -- and their neighbours by
+  // still lower ones.  Outlets on opposite faces of one axis never meet, so the chain is as long as the number of
+  // distinct AXES the outlets lie on, minus one.  Kernels exist for depth 0 (one outlet) and 1: any list of outlets on
+  // at most two axes (every 2-D flow; the reference takes any list, lettuce/_simulation.py:57-86).
+  {
+    int axes = 0;
+    for (int i = 0; i < d->n_boundaries; ++i)
+      if (d->boundaries[i].kind == LT_BOUNDARY_ABB_OUTLET) axes |= 1 << d->boundaries[i].axis;
+    const int n_axes = (axes & 1) + ((axes >> 1) & 1) + ((axes >> 2) & 1);
+    p->abb_depth = n_abb <= 1 ? 0 : (n_axes <= 2 ? 1 : n_axes - 1);
+    if (p->abb_depth > 1) {
+      lt_plan_destroy(p);
+      return fail(LT_ERR_UNSUPPORTED, "AntiBounceBackOutlets on all three axes (their planes meet in corners, where an "
+                                      "outlet's neighbour depends on two earlier outlets) are not supported by the HIP "
+                                      "engine; outlets on one or two axes are, in any number");
+    }
+  }
   const size_t bt_size = d->dtype == LT_F32 ? sizeof(lt::BoundaryTable<float>)
                                             : sizeof(lt::BoundaryTable<double>);
   if (hipMalloc(&p->bt, bt_size) != hipSuccess ||
@@ -1040,7 +1056,7 @@ const char *lt_plan_kernel_name(lt_plan *p) {
   a.mode = (two_step_wanted(p) || p->desc.ghost_planes == 2) ? lt::kFusedTwice : lt::kFused;
   if (many_step_wanted(p)) a.mode = lt::kFusedMany;
   a.masked = p->masked;
-  a.abb_depth = p->n_abb > 1 ? p->n_abb - 1 : 0;
+  a.abb_depth = p->abb_depth;
   a.abb_axis = p->masked ? masked_two_step_axis(p) : 2;
   a.strip = p->unit.d == 2 ? two_step_tile(p).width : 0;
   if (a.mode == lt::kFusedTwice && !p->unit.name(a)) a.mode = lt::kFused;

@@ -302,7 +302,7 @@ def operator_cases():
 
 
 # --------------------------------------------------------------------------- #
-def two_outlets_case(name, res, stencil, dt):
+def two_outlets_case(name, res, stencil, dt, outlets=None):
     """A flow with TWO anti-bounce-back outlets (+x and +y faces, which meet in an edge), an equilibrium
     inlet on x = 0 and a bounce-back block: the reference accepts any list of boundaries
     (lettuce/_simulation.py:57-86); among equal classes the order is that of the objects' addresses
@@ -322,10 +322,12 @@ def two_outlets_case(name, res, stencil, dt):
                 block = torch.zeros(self.resolution, dtype=torch.bool)
                 block[tuple(slice(n // 2 - 1, n // 2 + 1) for n in self.resolution)] = True
                 inlet = [0.3] + [0.0] * (d - 1)
-                self.made = [lt.EquilibriumBoundaryPU(self.context, torch.abs(x) < 1e-6, inlet),
-                             lt.AntiBounceBackOutlet([1] + [0] * (d - 1), self),
-                             lt.AntiBounceBackOutlet([0, 1] + [0] * (d - 2), self),
-                             lt.BounceBackBoundary(block)]
+                # default: +x and +y; `outlets` (round 3): any list of directions, e.g. +x, +y, -y -- three outlets on
+                # two axes, whose planes meet pairwise in edges
+                dirs = outlets if outlets is not None else [[1] + [0] * (d - 1), [0, 1] + [0] * (d - 2)]
+                self.made = ([lt.EquilibriumBoundaryPU(self.context, torch.abs(x) < 1e-6, inlet)]
+                             + [lt.AntiBounceBackOutlet(list(v), self) for v in dirs]
+                             + [lt.BounceBackBoundary(block)])
             return self.made
     flow = quiet(TwoOutlets, ctx, res, 100, 0.05, stencil)
     tau = flow.units.relaxation_parameter_lu
@@ -437,6 +439,10 @@ if __name__ == "__main__":
     two_outlets_case("two_outlets_d2q9_bgk_f64", [12, 10], lt.D2Q9(), "f64")
     two_outlets_case("two_outlets_d3q19_bgk_f64", [8, 7, 6], lt.D3Q19(), "f64")
     two_outlets_case("two_outlets_d3q19_bgk_f32", [8, 7, 6], lt.D3Q19(), "f32")
+    two_outlets_case("three_outlets_d2q9_bgk_f64", [12, 10], lt.D2Q9(), "f64", outlets=[[1, 0], [0, 1], [0, -1]])
+    two_outlets_case("three_outlets_d3q19_bgk_f32", [8, 7, 6], lt.D3Q19(), "f32", outlets=[[1, 0, 0], [0, 0, 1], [0, 0, -1]])
+    two_outlets_case("four_outlets_d3q27_bgk_f64", [6, 8, 7], lt.D3Q27(), "f64",
+                     outlets=[[0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]])
     if wanted("native") or wanted("hand"):
         hand_set_cases()
     if wanted("operators"):
