@@ -1105,7 +1105,7 @@ int lt_probe_copy(void *dst, const void *src, int64_t n_bytes, int32_t cache_pol
 
 int lt_plan_set_shift_policy(lt_plan *p, int32_t policy) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
-  if (policy < 0 || policy > 4) return fail(LT_ERR_INVALID, "shift policy %d", policy);
+  if (policy < 0 || policy > 5) return fail(LT_ERR_INVALID, "shift policy %d", policy);
   p->shift = policy;
   return LT_OK;
 }
