@@ -315,7 +315,7 @@ int resident_alloc(lt_plan *p) {
 
 // the two-step tile (the rule of unit.inc): rows of 256 bytes, 8 or 4 of them; rows = 0: no kernel
 struct TwoStepTile { int width, rows; };
-TwoStepTile two_step_tile_of(int d, int q, int esize, int n0) {
+TwoStepTile two_step_tile_of(int d, int q, int esize, int n0, bool masked = false) {
   if (d == 2) {
     // 2-D (twostep2d.hpp): strips of `width` columns, the widest that divides the contiguous extent; one "row"
     for (int w = 512; w >= 64; w /= 2)
@@ -324,11 +324,20 @@ TwoStepTile two_step_tile_of(int d, int q, int esize, int n0) {
   }
   const long long per_node = (long long)esize * 3 * q;
   const int width = 256 / esize;
-  const int rows = per_node * (width + 2) * 10 <= 160 * 1024
-                       ? 8 : (esize == 4 && per_node * (width + 2) * 6 <= 160 * 1024 ? 4 : 0);
+  int rows = per_node * (width + 2) * 10 <= 160 * 1024
+                 ? 8 : (esize == 4 && per_node * (width + 2) * 6 <= 160 * 1024 ? 4 : 0);
+  if (masked && rows == 8) {
+    // with boundaries the downward populations have a third LDS slot (lbm2m_kernel): where 8 rows then exceed
+    // the 160 KB, 4 rows are used (D3Q19 fp64: 168.6 KB -> 32 x 4 tiles, 101 KB); unit.inc applies the same rule
+    const int in_plane = q == 15 ? 5 : 9, crossing = (q - in_plane) / 2;
+    const long long lds8 = (long long)esize * ((width + 2) * 10 * (4 * crossing + 3 * in_plane + 3 * crossing) + 2 * q);
+    if (lds8 > 160 * 1024) rows = 4;
+  }
   return {width, rows};
 }
-TwoStepTile two_step_tile(const lt_plan *p) { return two_step_tile_of(p->unit.d, p->unit.q, p->esize, p->n0); }
+TwoStepTile two_step_tile(const lt_plan *p) {
+  return two_step_tile_of(p->unit.d, p->unit.q, p->esize, p->n0, p->masked != 0);
+}
 
 // The 3-D two-step kernels address with 32-bit byte offsets: lbm2_kernel within a plane, lbm2m_kernel (buffer
 // instructions) within the whole field -- the rule of unit.inc's launch_twice / launch_twice_masked, which return
@@ -628,6 +637,10 @@ bool two_step_wanted(lt_plan *p) {
   // its multiply-adds differently in the two inlining contexts): never automatic, so that the result of n steps
   // does not depend on how the caller splits them into batches
   if (p->desc.collision == LT_COLLISION_KBC) return false;
+  // fp64 plans with boundaries whose tile has only 4 rows (D3Q19: the third downward slot does not fit beside 8) are
+  // slower than one update per launch: Obstacle D3Q19 256^3 fp64 1.009 against 0.880 ms per update
+  // (tools/fp64_masked_two_step_probe.py; 4 waves per workgroup, 1.6 x redundant first step) -- opt-in only
+  if (p->masked && p->esize == 8 && p->unit.d == 3 && two_step_tile(p).rows == 4) return false;
   const long long bytes = 2ll * p->unit.q * p->N * p->esize;
   return bytes > (128ll << 20);
 }
@@ -1331,7 +1344,7 @@ int lt_two_step_limits(const lt_plan_desc *d, int32_t masked, int32_t *tile_widt
   else if (unit.d == 2) { e0 = d->shape[1]; e1 = d->shape[0]; e2 = 1; }
   else if (d->layout == LT_LAYOUT_REFERENCE) { e0 = d->shape[2]; e1 = d->shape[1]; e2 = d->shape[0]; }
   else { e0 = d->shape[0]; e1 = d->shape[1]; e2 = d->shape[2] + 2 * d->ghost_planes; }
-  const TwoStepTile tile = unit.d >= 2 ? two_step_tile_of(unit.d, unit.q, esize, (int)e0) : TwoStepTile{0, 0};
+  const TwoStepTile tile = unit.d >= 2 ? two_step_tile_of(unit.d, unit.q, esize, (int)e0, masked != 0) : TwoStepTile{0, 0};
   if (tile_width) *tile_width = tile.width;
   if (tile_rows) *tile_rows = tile.rows;
   if (addressable) *addressable = two_step_addressable(unit.d, unit.q, esize, e0, e1, e2, masked != 0) ? 1 : 0;

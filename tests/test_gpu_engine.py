@@ -546,7 +546,10 @@ def _masked_case(lat, res, dtype, abb, seed, with_field=False, abb_first=False, 
 MASKED_TWO_STEP = [("D3Q19", [8, 16, 64], "f32", (0, 1)), ("D3Q19", [8, 16, 64], "f32", (0, -1)), ("D3Q19", [6, 8, 128], "f32", (1, 1)),
                    ("D3Q19", [6, 16, 64], "f32", (0, 1)), ("D3Q19", [7, 8, 64], "f32", (0, 1)), ("D3Q19", [4, 8, 64], "f32", (2, -1)),
                    ("D3Q19", [5, 8, 64], "f32", None), ("D3Q27", [6, 8, 64], "f32", (0, 1)), ("D3Q27", [5, 4, 64], "f32", None),
-                   ("D3Q15", [6, 8, 64], "f32", (0, 1)), ("D3Q15", [6, 8, 32], "f64", (0, 1)), ("D3Q15", [5, 8, 32], "f64", None)]
+                   ("D3Q15", [6, 8, 64], "f32", (0, 1)), ("D3Q15", [6, 8, 32], "f64", (0, 1)), ("D3Q15", [5, 8, 32], "f64", None),
+                   # round 3: D3Q19 fp64 with boundaries on 32 x 4 tiles (8 rows need 168.6 KB of LDS with the third
+                   # slot of the downward populations)
+                   ("D3Q19", [6, 8, 32], "f64", (0, 1)), ("D3Q19", [5, 4, 64], "f64", None), ("D3Q19", [4, 12, 32], "f64", (0, 1))]
 
 
 @pytest.mark.parametrize("lat,res,dt,abb", MASKED_TWO_STEP, ids=[f"{t[0]}-{'x'.join(map(str, t[1]))}-{t[2]}-{t[3]}" for t in MASKED_TWO_STEP])
@@ -567,7 +570,8 @@ def test_masked_two_step_launch_is_bit_identical_to_two_masked_single_steps(lat,
 
 MASKED_TWO_STEP_ROWS = [("D3Q19", [4, 8, 64], "f32", (2, 1)), ("D3Q19", [4, 8, 64], "f32", (2, -1)), ("D3Q19", [5, 16, 128], "f32", (2, 1)),
                         ("D3Q19", [6, 16, 128], "f32", (2, -1)), ("D3Q27", [5, 4, 64], "f32", (2, 1)), ("D3Q27", [4, 8, 128], "f32", (2, -1)),
-                        ("D3Q15", [5, 8, 64], "f32", (2, 1)), ("D3Q15", [5, 8, 32], "f64", (2, 1)), ("D3Q15", [4, 16, 64], "f64", (2, -1))]
+                        ("D3Q15", [5, 8, 64], "f32", (2, 1)), ("D3Q15", [5, 8, 32], "f64", (2, 1)), ("D3Q15", [4, 16, 64], "f64", (2, -1)),
+                        ("D3Q19", [5, 8, 32], "f64", (2, 1)), ("D3Q19", [4, 4, 64], "f64", (2, -1))]
 
 
 @pytest.mark.parametrize("lat,res,dt,abb", MASKED_TWO_STEP_ROWS, ids=[f"{t[0]}-{'x'.join(map(str, t[1]))}-{t[2]}-{t[3]}" for t in MASKED_TWO_STEP_ROWS])
