@@ -128,6 +128,10 @@ _LIB = None
 
 
 def library_path() -> str:
+    """the in-tree library; LT_ENGINE_LIBRARY names another build of it (A/B experiments with compiler flags)"""
+    override = os.environ.get("LT_ENGINE_LIBRARY")
+    if override:
+        return override
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblettuce_hip.so")
 
 

@@ -136,7 +136,10 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   // (test_obstacle_on_slabs_with_two_updates_per_launch[4-...-D3Q27]).  The other instantiations keep the two-copy
   // form, which their bit-identity tests cover (random masks, inlet faces, the reference's Obstacle vectors) and which
   // is the faster one: Obstacle D3Q27 256^3 BGK in the reference layout 0.48-0.49 against 0.514 ms per update.
-  constexpr bool ONE_ROLE = S::Q >= 27 && LAYOUT == 1;
+#ifndef LT_FORCE_TWO_ROLES
+#define LT_FORCE_TWO_ROLES 0      // 1: the two-copy form everywhere (reproduces the defect: tools/debug_obst27b.py)
+#endif
+  constexpr bool ONE_ROLE = S::Q >= 27 && LAYOUT == 1 && !LT_FORCE_TWO_ROLES;
   __shared__ T lds_u[4][NU][NI];
   __shared__ T lds_c[3][NC][NI];
   __shared__ T lds_d[3][ND][NI];
