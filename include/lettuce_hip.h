@@ -317,7 +317,8 @@ const char *lt_plan_kernel_name(lt_plan *plan);
  * element, 1 = unaligned vector load, 2 = aligned vector load + cross-lane shift.  Two-step kernel
  * (D3Q19 / D3Q15 fp32, BGK, reference layout): 0 = product variant, 1 = two nodes per thread in both
  * phases, 2 = two output nodes per thread, 3 = no XCD-aware renumbering of the workgroups, 4 = the round-1
- * renumbering (an eighth of the grid per XCD instead of an eighth of every segment layer). */
+ * renumbering (an eighth of the grid per XCD instead of an eighth of every segment layer), 5 = 32 x 8 tiles for
+ * the slab edge launch (two workgroups per CU; measured slower: 99 against 77 us). */
 int lt_plan_set_shift_policy(lt_plan *plan, int32_t policy);
 /* Diagnostic: dst[0:n_bytes] = src[0:n_bytes] with 16-byte accesses and the cache-policy bits of
  * lt_plan_set_tuning; max_blocks > 0 caps its grid (grid-stride loop).  bench.py uses it to
