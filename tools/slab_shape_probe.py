@@ -27,7 +27,11 @@ def timed(plan, f, g, reps=8):
     return best
 
 
-for nx, ny, nz, seg, pad in ((256, 256, 256, 128, 0), (256, 256, 256, 128, 32832), (512, 256, 128, 64, 0), (512, 256, 128, 64, 32832),
+import sys as _sys
+SHAPES = ((512, 512, 64, 64, 32832), (512, 504, 64, 64, 32832), (512, 520, 64, 64, 32832), (512, 528, 64, 64, 32832),
+          (512, 496, 64, 64, 32832), (512, 544, 64, 64, 32832), (576, 512, 64, 64, 32832), (448, 512, 64, 64, 32832),
+          (512, 512, 64, 64, 32832)) if len(_sys.argv) > 1 and _sys.argv[1] == "planes" else None
+for nx, ny, nz, seg, pad in SHAPES or ((256, 256, 256, 128, 0), (256, 256, 256, 128, 32832), (512, 256, 128, 64, 0), (512, 256, 128, 64, 32832),
                              (512, 512, 64, 64, 0), (512, 512, 64, 64, 32832), (512, 512, 64, 32, 32832),
                              (1024, 512, 32, 32, 32832), (1024, 1024, 16, 16, 32832), (256, 512, 128, 64, 32832),
                              (256, 1024, 64, 64, 32832), (128, 1024, 128, 64, 32832), (64, 2048, 128, 64, 32832)):
