@@ -34,8 +34,9 @@ def pmc(path):
 
 
 def first(pattern):
-    files = glob.glob(pattern)
-    return files[0] if files else None
+    """the newest match: gpurun merges every session of a tag into the same directory"""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1] if files else None
 
 
 def stats_rows(path, others=0):
