@@ -36,14 +36,14 @@ exceeds its wall budget (checked on the host between batches; a watchdog thread 
 returns), rank 0 still prints the held line with the failure recorded in ``config.transport`` and all ranks
 exit 0.  Nothing is re-executed and no process that has touched the GPU is restarted.
 
-roofline: HBM-bound kernel.  ``achieved`` = the bytes a launch of the dominant kernel has to move
-through HBM -- every population read once and written once, 2 * 19 * 4 = 152 B per node and
-launch, however many lattice updates the launch performs on them -- divided by
-its average duration, measured with HIP events recorded on the launch stream around the fused
-launches of the median batch.  ``frac`` = achieved / 8 TB/s, a physical HBM fraction (<= 1).  The
-two-step kernel does two lattice updates per launch with the intermediate state in LDS; the rate
-in algorithmic bytes of lattice updates (152 B per node and UPDATE, SURVEY 8(d)'s figure) is reported
-as ``algorithmic_update_GBps`` / ``algorithmic_frac`` and may exceed the HBM peak.  ``traffic`` = HBM
+roofline: HBM-bound kernel.  ``achieved`` = ALGORITHMIC bytes per launch of the dominant kernel --
+SURVEY.md 8(d)'s 2 * 19 * 4 = 152 B per lattice update x the lattice updates one launch performs (nodes x
+``lattice_updates_per_node_per_launch``) -- divided by the launch's average duration, measured with HIP
+events recorded on the launch stream around the fused launches of the median batch; ``frac`` =
+achieved / 8 TB/s.  The two-step kernel performs two lattice updates per node and launch with the
+intermediate state in LDS, so HBM carries every population once in and once out per TWO updates and
+``frac`` can exceed 1; what HBM physically has to carry per second (populations read once + written
+once per launch / launch time, <= the peak) is ``physical_GBps`` / ``physical_frac``.  ``traffic`` = HBM
 bytes per launch from the rocprofv3 PMC passes in profiles/traffic.json, used only if that file was
 produced from the kernel sources of this build (hash of lettuce_amd/csrc), else null.
 verified: after the timed batches the same steps are repeated, untimed, from a copy of the
@@ -496,15 +496,17 @@ def single_gpu_bench(args, lt, device):
         updates_per_launch = 2 if paired else 1
         fused_ms = batch_fused_ms[mid] / launches
         hbm_bytes = bytes_per_node * nodes                     # one read + one write of every population
-        achieved = hbm_bytes / (fused_ms * 1e-3) / 1e9
+        physical = hbm_bytes / (fused_ms * 1e-3) / 1e9
+        achieved = physical * updates_per_launch               # 152 B per node and lattice UPDATE
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic_from_profile(kernel),
                     "kernel": kernel, "avg_launch_ms": round(fused_ms, 5),
-                    "hbm_bytes_per_launch_required": hbm_bytes,
+                    "algorithmic_bytes_per_launch": hbm_bytes * updates_per_launch,
                     "lattice_updates_per_node_per_launch": updates_per_launch,
-                    "algorithmic_update_GBps": round(achieved * updates_per_launch, 1),
-                    "algorithmic_frac": round(achieved * updates_per_launch / HBM_PEAK_GBS, 4),
+                    "hbm_bytes_per_launch_required": hbm_bytes,
+                    "physical_GBps": round(physical, 1),
+                    "physical_frac": round(physical / HBM_PEAK_GBS, 4),
                     "launches_timed": launches, "source_hash": source_hash(),
                     "populations": (f"engine-owned ping-pong buffers, {resident_stride - nodes} elements of padding between "
                                     f"populations (lt_resident_*); flow.f / flow.f_next stay the reference's dense "
@@ -514,13 +516,14 @@ def single_gpu_bench(args, lt, device):
             real = roofline["traffic"] / (fused_ms * 1e-3) / 1e9
             roofline["hbm_traffic_GBps"] = round(real, 1)
             roofline["hbm_traffic_frac_of_peak"] = round(real / HBM_PEAK_GBS, 4)
-        roofline["note"] = ("achieved / frac = populations read once + written once per launch / launch time (a physical "
-                            "HBM rate, <= 1)" + ("; the launch performs two lattice updates per node with the intermediate "
-                                                 "state in LDS: algorithmic_update_GBps / algorithmic_frac count SURVEY "
-                                                 "8(d)'s 152 B per node and UPDATE and may exceed the peak"
-                                                 if paired else ""))
+        roofline["note"] = ("achieved / frac = SURVEY 8(d)'s 152 B per node and lattice update x the updates of one launch / "
+                            "launch time" + ("; the launch performs two lattice updates per node with the intermediate "
+                                             "state in LDS, so frac may exceed 1: physical_GBps / physical_frac = "
+                                             "populations read once + written once per launch / launch time is the rate "
+                                             "HBM has to sustain (<= peak), hbm_traffic_* what the PMC counters saw"
+                                             if paired else ""))
         roofline["copy_ceiling_GBps"] = round(ceiling, 1)
-        roofline["frac_of_copy_ceiling"] = round(achieved / ceiling, 4)
+        roofline["physical_frac_of_copy_ceiling"] = round(physical / ceiling, 4)
         # ---- self-check of the timed result (untimed) ------------------------------------------
         mass = float(sim._native.plan.mass(flow.f))             # device reductions (lt_mass, lt_kinetic_energy)
         energy = float(lt.IncompressibleKineticEnergy(flow)())
@@ -701,16 +704,16 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
         elapsed = batch_s[mid]
         mlups = args.steps * nodes_per_rank * world / 1e6 / elapsed
         # per-rank fused-kernel rate is not separable from the exchange here: the whole-step rate of one rank.
-        # achieved = bytes HBM has to carry (populations read once + written once per LAUNCH; the two-step driver
-        # does two lattice updates per launch) / time, a physical rate like the N = 1 line's
+        # achieved = SURVEY 8(d)'s bytes per node and lattice update x updates / time, like the N = 1 line's; the
+        # two-step driver does two updates per launch, so HBM physically carries half of that
         eff = bytes_per_node * nodes_per_rank * args.steps / elapsed / 1e9
         per_launch = 2 if driver == "two-step" else 1
-        roofline = {"bound": "hbm", "achieved": round(eff / per_launch, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(eff / per_launch / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
-                    "lattice_updates_per_node_per_launch": per_launch, "algorithmic_update_GBps": round(eff, 1),
-                    "algorithmic_frac": round(eff / HBM_PEAK_GBS, 4),
-                    "note": "whole-step rate per GPU (includes the halo exchange): populations read once + written once "
-                            f"per launch / time; algorithmic_update_GBps counts {bytes_per_node} B per node and update"}
+        roofline = {"bound": "hbm", "achieved": round(eff, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(eff / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
+                    "lattice_updates_per_node_per_launch": per_launch, "physical_GBps": round(eff / per_launch, 1),
+                    "physical_frac": round(eff / per_launch / HBM_PEAK_GBS, 4),
+                    "note": f"whole-step rate per GPU (includes the halo exchange): {bytes_per_node} B per node and lattice "
+                            "update / time; physical_* = populations read once + written once per launch / time"}
         return {
             "metric": "MLUPS (million lattice updates/s) D3Q19 256³ TGV; achieved HBM GB/s vs peak",
             "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
