@@ -34,7 +34,9 @@ probe has finished, and that line is HELD.  A later candidate replaces it only i
 it after the warm-up probe AND after its own timed batches, and faster; if one raises, is rejected, or
 exceeds its wall budget (checked on the host between batches; a watchdog thread covers a call that never
 returns), rank 0 still prints the held line with the failure recorded in ``config.transport`` and all ranks
-exit 0.  Nothing is re-executed and no process that has touched the GPU is restarted.
+exit 0.  Nothing is re-executed and no process that has touched the GPU is restarted.  The first candidate has a
+budget too (--first-candidate-budget, 600 s): if IT never returns, every rank ends itself (exit code 3) and rank 0
+prints a line with value 0 and the reason rather than hanging until the caller's limit.
 
 roofline: HBM-bound kernel.  ``achieved`` = ALGORITHMIC bytes per launch of the dominant kernel --
 SURVEY.md 8(d)'s 2 * 19 * 4 = 152 B per lattice update x the lattice updates one launch performs (nodes x
@@ -117,6 +119,11 @@ def parse(argv=None):
     ap.add_argument("--candidate-budget", type=float, default=float(os.environ.get("LT_BENCH_CANDIDATE_BUDGET", "120")),
                     help="slab path: wall seconds a candidate after the first may take (checked between batches; "
                          "a watchdog prints the held line and ends the rank 60 s later if a call never returns)")
+    ap.add_argument("--first-candidate-budget", type=float,
+                    default=float(os.environ.get("LT_BENCH_FIRST_BUDGET", "600")),
+                    help="N > 1: wall seconds the first (reference) candidate may take; past it (+ the grace) every rank "
+                         "ends itself and rank 0 prints a line with value 0 and the reason, instead of hanging until "
+                         "somebody else's limit")
     ap.add_argument("--watchdog-grace", type=float, default=60.0,
                     help="slab path: seconds past a candidate's budget after which the watchdog prints the held line "
                          "and ends the rank")
@@ -373,9 +380,11 @@ class HeldLine:
     """The line rank 0 will print, replaced only by better candidates; a watchdog prints it and ends the rank when
     a candidate call does not return."""
 
-    def __init__(self, rank):
+    def __init__(self, rank, nothing_held=None):
         self.rank, self.line, self.lock, self.printed = rank, None, threading.Lock(), False
         self.deadline, self.what = None, ""
+        # nothing_held(why) -> the line to print when no candidate has produced one: value 0 and the reason
+        self.nothing_held = nothing_held
         self._thread = threading.Thread(target=self._watch, daemon=True)
         self._thread.start()
 
@@ -393,14 +402,29 @@ class HeldLine:
             if self.rank == 0 and self.line is not None:
                 print(json.dumps(self.line), flush=True)
 
+    def emit_nothing(self, why):
+        """no candidate produced a line: rank 0 says so in the line's own format (value 0)"""
+        with self.lock:
+            if self.printed:
+                return
+            self.printed = True
+            if self.rank == 0 and self.nothing_held is not None:
+                print(json.dumps(self.nothing_held(why)), flush=True)
+
     def _watch(self):
         while True:
             time.sleep(1.0)
             d = self.deadline
-            if d is not None and time.time() > d and self.line is not None:
+            if d is None or time.time() <= d:
+                continue
+            if self.line is not None:
                 self.line["config"]["transport"]["aborted"] = f"{self.what}: no return within its budget; held line printed by the watchdog"
                 self.emit()
                 os._exit(0)
+            # the reference candidate itself never came back: end the rank (every rank has the same deadline) rather
+            # than hang until the caller's limit
+            self.emit_nothing(f"{self.what}: no return within its budget and no line held; ended by the watchdog")
+            os._exit(3)
 
 
 def main():
@@ -680,8 +704,19 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
     returns a slab driver (callable with a step count, ``local_f()``, ``engine.kernel_name()``)."""
     world, rank, device = ranks.world, ranks.rank, ranks.device
     barrier, all_ranks, max_over_ranks = ranks.barrier, ranks.all_ranks, ranks.max_over_ranks
-    held = HeldLine(rank)
     probe, checks, failures = {}, {}, {}
+
+    def nothing_held(why):
+        return {"metric": "MLUPS (million lattice updates/s) D3Q19 256³ TGV; achieved HBM GB/s vs peak",
+                "value": 0.0, "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": dtype_tag, "data": "synthetic",
+                "config": {"workload": what, "global_resolution": global_res, "parallelism": f"z-slab x{world}",
+                           "transport": {"chosen": None, "warmup_ms_per_step": probe, "checks": checks,
+                                         "failures": failures, "ranks_seen": world, "aborted": why}},
+                "roofline": None, "cpu_baseline": None, "verified": None}
+
+    held = HeldLine(rank, nothing_held)
     reference = {}                     # the first candidate's populations after the probe and after its timed batches
     probe_steps = max(args.warmup, 60) if probe_steps is None else probe_steps
     window_ok = None
@@ -741,13 +776,12 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
         name = f"{driver}/{transport}"
         first = index == 0
         started = time.time()
-        budget = None if first else args.candidate_budget
-        if budget is not None:
-            held.arm(budget + args.watchdog_grace, name)
+        budget = args.first_candidate_budget if first else args.candidate_budget
+        held.arm(budget + args.watchdog_grace, name)
 
         def over_budget():
             """between batches: has ANY rank used up this candidate's wall budget?  (collective)"""
-            return budget is not None and not all_ranks(time.time() - started <= budget)
+            return not all_ranks(time.time() - started <= budget)
 
         try:
             if transport.startswith("window"):
@@ -871,6 +905,7 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
             held.disarm()
 
     if held.line is None:
+        held.emit_nothing("no usable slab configuration")
         raise SystemExit(f"no usable slab configuration: {failures}")
     held.emit()
     reference.clear()

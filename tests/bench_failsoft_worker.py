@@ -49,7 +49,9 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     args = bench.parse(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--batches", "2",
-                        "--candidate-budget", "2", "--watchdog-grace", "2"])
+                        "--candidate-budget", "2", "--watchdog-grace", "2", "--first-candidate-budget", "20"])
+    if "first-never-returns" in stubs:
+        args.first_candidate_budget = 2.0
     bench.MIN_BATCH_S = 0.0
     ctx = lt.Context("cpu", torch.float64, use_native=False)
     res = [8, 4, 8 * world]
@@ -72,7 +74,10 @@ def main():
             return Misbehaving(sim, transport, 10 ** 9)
         return sim
 
-    wanted = [("single-step", "rccl")] + [("two-step", t) for t in stubs]
+    if "first-never-returns" in stubs:          # the reference candidate itself hangs in its first timed batch
+        wanted = [("single-step", "never-returns"), ("two-step", "rccl")]
+    else:
+        wanted = [("single-step", "rccl")] + [("two-step", t) for t in stubs]
     ranks = bench.Ranks(dist, world, rank, 0, torch.device("cpu"))
     bench.candidate_loop(args, ranks, wanted, build, "stub workload", res, res[0] * res[1] * slab.nz_local, 304, "f64",
                          probe_steps=2)

@@ -67,3 +67,15 @@ def test_a_candidate_that_never_returns_ends_in_the_held_line():
     line, t = _check_line(lines)
     assert t["chosen"] == "single-step/rccl"
     assert "watchdog" in t["aborted"]
+
+
+def test_a_reference_candidate_that_never_returns_ends_in_a_line_that_says_so():
+    """the first candidate hangs (RCCL's first point-to-point call on a node, say): every rank ends itself after the
+    first candidate's budget and rank 0 prints a line with value 0 and the reason -- no hang until the caller's limit"""
+    r, lines = _run("first-never-returns", timeout=120)
+    assert r.returncode != 0
+    assert len(lines) == 1, (lines, r.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] == 0.0
+    t = line["config"]["transport"]
+    assert t["chosen"] is None and "watchdog" in t["aborted"] and "single-step/never-returns" in t["aborted"]
