@@ -67,6 +67,15 @@ typedef const char *(*NameFn)(const StepArgs &);
   int aux_##tag(const AuxArgs &);         \
   const char *name_##tag(const StepArgs &);
 
+// the unmasked 3-D two-step launches of a unit, instantiated by inst2_<tag>.hip (unit.inc, LT_PART)
+#define LT_DECLARE_TWICE(tag) int twice_##tag(const StepArgs &, bool name_only, const char **name);
+LT_DECLARE_TWICE(d3q15_f32)
+LT_DECLARE_TWICE(d3q15_f64)
+LT_DECLARE_TWICE(d3q19_f32)
+LT_DECLARE_TWICE(d3q19_f64)
+LT_DECLARE_TWICE(d3q27_f32)
+LT_DECLARE_TWICE(d3q27_f64)
+
 LT_DECLARE_UNIT(d1q3_f32)
 LT_DECLARE_UNIT(d1q3_f64)
 LT_DECLARE_UNIT(d3q15_f32)

@@ -1,8 +1,8 @@
-// Kernel instantiations: D3Q27, float.
+// Kernel instantiations: D3Q27, float.  Part 2: the unmasked two-step launches (unit.inc, LT_PART).
 #define LT_S lt::D3Q27
 #define LT_T float
 #define LT_TAG d3q27_f32
 #define LT_HAS_KBC 1
 #define LT_IS_3D 1
-#define LT_PART 1
+#define LT_PART 2
 #include "unit.inc"
