@@ -1,3 +1,6 @@
+"""fp64 one-step kernels of the D3Q19 unit (cfg5's shape with the two-step kernel switched off, and the Obstacle with
+its masked kernel): ms per update.  Used with LT_ENGINE_LIBRARY to check what a compiler setting tried on the two-step
+kernel does to the other kernels of the unit (round 3: max-ilp costs the masked kernel 8 %, hence its own object)."""
 import sys, os, json
 sys.path.insert(0, os.getcwd())
 import torch, lettuce_amd as lt
