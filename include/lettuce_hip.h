@@ -336,6 +336,13 @@ int lt_plan_set_graph_mode(lt_plan *plan, int32_t mode);
  * wide != 0 switches the hot kernel (fused, BGK, no masks) to its 16-byte-per-lane A/B variant,
  * whose shift handling lt_plan_set_shift_policy selects. */
 int lt_plan_set_tuning(lt_plan *plan, int32_t cache_policy, int32_t wide);
+/* THREE fused stream-collide steps in one launch (lbm3_kernel): out = (C S)^3 f with both intermediate states in
+ * LDS -- one HBM read and one write of the populations per three lattice updates.  Periodic 3-D plans without
+ * boundaries in the reference layout whose grid tiles (contiguous extent % 64 (fp32) / 32 (fp64), middle extent % 4);
+ * LT_ERR_UNSUPPORTED otherwise.  Bit-identical to three lt_stream_collide calls.  Same contract as the reference's
+ * native step applied three times (lettuce/cuda_native/_template.py:58-86). */
+int lt_stream_collide_thrice(lt_plan *plan, const void *f_dev, void *out_dev, double tau, void *stream);
+
 /* Two fused steps in one launch: out = (C S)^2 f for the whole periodic grid, the intermediate
  * state staged through LDS (one HBM read and one write of the populations per two lattice updates).
  * Bit-identical to two lt_stream_collide calls.  Exists with BGK / no collision for the 3-D lattices

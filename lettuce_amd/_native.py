@@ -92,6 +92,7 @@ SYMBOLS = {
     "lt_plan_set_graph_mode": (ctypes.c_int, [_vp, _i32]),
     "lt_plan_set_tuning": (ctypes.c_int, [_vp, _i32, _i32]),
     "lt_plan_set_residency": (ctypes.c_int, [_vp, _i32]),
+    "lt_stream_collide_thrice": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _vp]),
     "lt_stream_collide_twice": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _vp]),
     "lt_plan_set_two_step": (ctypes.c_int, [_vp, _i32, _i32]),
     "lt_stream_collide_twice_planes": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _i64, _vp]),
@@ -606,6 +607,14 @@ class Plan:
     def set_two_step(self, mode: int = -1, planes_per_workgroup: int = 0):
         """lt_run pairs fused steps into two-step launches: -1 automatic, 0 never, 1 when supported"""
         self._check(self.lib.lt_plan_set_two_step(self._handle, int(mode), int(planes_per_workgroup)))
+
+    @_on_device
+    def stream_collide_thrice(self, f, out, tau):
+        """out = (collide o stream)^3 f in one launch (both intermediate states in LDS; lbm3_kernel)"""
+        self._tensor_ok(f, self.f_shape); self._tensor_ok(out, self.f_shape)
+        self._check(self.lib.lt_stream_collide_thrice(self._handle, _ptr(f), _ptr(out), float(tau),
+                                                      _stream_handle()))
+        return out
 
     @_on_device
     def stream_collide_twice(self, f, out, tau):

@@ -379,6 +379,24 @@ int resolve_seg_len(const lt_plan *p, int planes) {
   return best;
 }
 
+// planes per workgroup of the three-step kernel (lbm3_kernel: tiles of 64 / 32 x 4 nodes, one workgroup per CU, a
+// segment of L planes computes L + 4 level-1 and L + 2 level-2 planes)
+int resolve_seg_len3(const lt_plan *p, int planes) {
+  const int width = 256 / p->esize;
+  const long long tiles = (long long)(p->n0 / width) * (p->n1 / 4);
+  const long long cus = p->n_cu > 0 ? p->n_cu : 256;
+  int best = 1;
+  double best_score = -1.0;
+  for (int len = 1; len <= planes; ++len) {
+    if (planes % len) continue;
+    const long long blocks = tiles * (planes / len);
+    const long long rounds = (blocks + cus - 1) / cus;
+    const double score = ((double)len / (double)(len + 3)) * ((double)blocks / (double)(rounds * cus));
+    if (score > best_score) { best_score = score; best = len; }
+  }
+  return best;
+}
+
 // Two-step slab halo: side -1 = lower cut, +1 = upper cut.  Packing reads the two interior planes
 // next to the cut, unpacking fills the two ghost planes beyond it.
 int halo2(lt_plan *p, bool do_pack, void *f, int side, void *buf, void *stream) {
@@ -510,6 +528,7 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.seg_len = mode == lt::kFusedTwice ? resolve_seg_len(p, p->unit.d == 2 ? p->n1 : a.planes) : 0;
   a.strip = p->unit.d == 2 ? two_step_tile(p).width : 0;
   if (mode == lt::kFusedTwice) a.shift = p->shift;      // tile-shape A/B variant
+  if (mode == lt::kFusedThrice) a.seg_len = p->seg_len > 0 && a.planes % p->seg_len == 0 ? p->seg_len : resolve_seg_len3(p, a.planes);
   if (mode == lt::kFusedMany) a.seg_len = p->many_now;
   a.stream = static_cast<hipStream_t>(stream);
   a.stride_in = p->stride_in_now >= 0 ? p->stride_in_now : p->pop_stride;
@@ -1213,6 +1232,12 @@ int lt_plan_set_graph_mode(lt_plan *p, int32_t mode) {
   return LT_OK;
 }
 
+int lt_stream_collide_thrice(lt_plan *p, const void *f, void *out, double tau, void *stream) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (p->unit.d != 3 || p->desc.ghost_planes || p->masked || p->desc.layout != LT_LAYOUT_REFERENCE)
+    return fail(LT_ERR_UNSUPPORTED, "three steps per launch: periodic 3-D plans without boundaries, reference layout");
+  return step(p, lt::kFusedThrice, f, out, tau, 0, p->n2, stream);
+}
 int lt_stream_collide_twice(lt_plan *p, const void *f, void *out, double tau, void *stream) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   const int g = p->desc.ghost_planes;

@@ -6,7 +6,7 @@
 
 namespace lt {
 
-enum StepMode { kFused = 0, kCollideOnly = 1, kStreamOnly = 2, kFusedTwice = 3, kFusedMany = 4 };
+enum StepMode { kFused = 0, kCollideOnly = 1, kStreamOnly = 2, kFusedTwice = 3, kFusedMany = 4, kFusedThrice = 5 };
 
 struct StepArgs {
   const void *in;

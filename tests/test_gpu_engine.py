@@ -1265,6 +1265,60 @@ def test_two_steps_per_launch_on_small_3d_grids_equal_single_steps(lat, dt, res,
         plan.stream_collide_many(f, c, 0.7, 3)
 
 
+@pytest.mark.parametrize("lat,dt", [("D3Q19", "f32"), ("D3Q19", "f64"), ("D3Q15", "f32")])
+@pytest.mark.parametrize("res,planes", [([8, 8, 64], 0), ([6, 12, 128], 0), ([16, 16, 64], 4), ([5, 4, 64], 1), ([64, 64, 128], 0)])
+@pytest.mark.parametrize("coll", ["bgk", "none"])
+def test_three_steps_per_launch_equal_three_single_steps(lat, dt, res, planes, coll):
+    """lbm3_kernel (round 3, threestep.hpp): three stream-collide steps per launch with BOTH intermediate states in LDS
+    (tiles of 64 / 32 x 4 nodes and their one- and two-node halos, sixteen waves with one phase -- or two -- each, two
+    barriers per plane): bit for bit three launches of the one-step kernel, for every segment length, on grids whose
+    halos wrap around onto the tile itself.  (Opt-in entry point: measured slower per update than two steps per
+    launch)"""
+    T = TORCH_DT[dt]
+    L = orc.LATTICES[lat]
+    if dt == "f64":
+        res = [res[0], res[1], max(32, res[2] // 2)]
+    plan = plan_for(lat, T, coll, res)
+    plan.set_two_step(1, planes)
+    torch.manual_seed(11)
+    w = torch.rand(L.q, 1, 1, 1, device="cuda", dtype=T) * 0.03 + 0.02
+    f = (w * (1 + 0.05 * torch.rand([L.q] + res, device="cuda", dtype=T))).contiguous()
+    a, b = f.clone(), torch.empty_like(f)
+    for _ in range(3):
+        plan.stream_collide(a, b, 0.7)
+        a, b = b, a
+    out = torch.empty_like(f)
+    plan.stream_collide_thrice(f, out, 0.7)
+    assert torch.equal(out, a)
+
+
+def test_three_steps_per_launch_reproduce_the_reference_vectors():
+    """... and chained: 3 x 3 steps through lbm3_kernel after the collide-only launch, then the streaming pass, against
+    the reference's populations after 10 steps (periodic BGK: bit for bit)."""
+    g = golden("tgv3d_d3q19_bgk_8x16x64_f32")
+    plan = plan_for("D3Q19", torch.float32, "bgk", g["f0"].shape[1:])
+    tau = float(g["tau"])
+    a = torch.tensor(g["f0"], device="cuda")
+    b = torch.empty_like(a)
+    plan.collide(a, b, tau)
+    for _ in range(3):
+        plan.stream_collide_thrice(b, a, tau)
+        a, b = b, a
+    plan.stream(b, a)
+    np.testing.assert_array_equal(a.cpu().numpy(), g["f10"])
+
+
+def test_three_steps_per_launch_are_refused_where_they_do_not_apply():
+    plan = plan_for("D3Q27", torch.float32, "bgk", [64, 8, 8])        # two levels of D3Q27 do not fit the LDS
+    f = torch.rand(plan.f_shape, device="cuda") * 0.01 + 0.03
+    with pytest.raises(Exception, match="no kernel"):
+        plan.stream_collide_thrice(f, torch.empty_like(f), 0.7)
+    plan = plan_for("D3Q19", torch.float32, "bgk", [8, 6, 64])        # middle extent % 4
+    f = torch.rand(plan.f_shape, device="cuda") * 0.01 + 0.03
+    with pytest.raises(Exception, match="no kernel"):
+        plan.stream_collide_thrice(f, torch.empty_like(f), 0.7)
+
+
 @pytest.mark.parametrize("name,dt,n", [("tgv3d_d3q19_bgk_32_f32", "f32", 10), ("tgv3d_d3q19_bgk_16_f64", "f64", 100)])
 def test_small_3d_grids_run_two_steps_per_launch_and_reproduce_the_reference(name, dt, n):
     """lt_run on a launch-bound 3-D grid with lt_plan_set_many_step(plan, 1) pairs its fused steps into

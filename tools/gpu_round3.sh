@@ -41,3 +41,4 @@ du -sh $OUT
 echo "== small grids" && timeout -k 10 300 python tools/small_grid_bench.py > $OUT/small_grids.jsonl 2> $OUT/small_grids.err; echo "rc $?"
 echo "== cfg4 with KBC in the two-step kernel" && timeout -k 10 300 python tools/kbc_two_step_probe.py > $OUT/kbc_two_step.jsonl 2> $OUT/kbc_two_step.err; echo "rc $?"
 echo "== other configs" && timeout -k 10 300 python tools/bench_configs.py cfg1 cfg4 cfg4bgk cfg4bgk1 obst19 obst19_1 cfg5 > $OUT/other_configs.jsonl 2> $OUT/other_configs.err; echo "rc $?"
+echo "== three steps per launch" && timeout -k 10 300 python tools/three_step_probe.py > $OUT/three_step.jsonl 2> $OUT/three_step.err; echo "rc $?"
