@@ -359,13 +359,24 @@ __device__ __forceinline__ T square_norm(const T (&u)[3]) {
 // the exact remainder x - q D by FMA, one correction step (Markstein).  Equal to x / D for every
 // fp32 x with |x / D| >= 1e-30 (exhaustive, tests/aux/exact_division_check.c) and in 6.4e9 random
 // fp64 quotients.
+// fp32 (round 3): TWO instructions -- x r_hi + RN(x r_lo) with r_hi + r_lo = 1 / D to twice the precision, one
+// rounding of a sum that is x / D to 2^-47 -- equal to x / D for EVERY fp32 x with |x / D| >= 1e-30 for these two
+// constants (exhaustive as well: exact_division_check f32two 1; the general argument does not exclude a quotient that
+// close to a rounding boundary, so fp64 keeps the three-instruction form, which Markstein's theorem covers).  The
+// equilibrium calls this 28 times per node: 7 % of the collision's issue slots.
 template <int WHICH, typename T>   // 0: D = 2 cs^2, 1: D = cs^2
 __device__ __forceinline__ T div_cs(T x) {
   constexpr T d = (T)(WHICH == 0 ? 2.0 * kCs2 : kCs2);
   constexpr T r = (T)(1.0 / (double)d);
-  const T q = x * r;
-  const T rem = fma_t(-q, d, x);
-  return fma_t(rem, r, q);
+  if constexpr (sizeof(T) == 4) {
+    constexpr T r_lo = (T)(1.0 / (double)d - (double)r);
+    const T low = x * r_lo;                           // rounded on its own: a product feeding an fma's addend
+    return fma_t(x, r, low);
+  } else {
+    const T q = x * r;
+    const T rem = fma_t(-q, d, x);
+    return fma_t(rem, r, q);
+  }
 }
 
 // QuadraticEquilibrium (lettuce/ext/_equilibrium/quadratic_equilibrium.py:15-24), u along
@@ -389,9 +400,11 @@ template <typename T, class S, int LAYOUT, int q>
 __device__ __forceinline__ void feq_pair(T rho, const T (&u)[3], T uxu, T &fq, T &fo) {
 #pragma clang fp contract(off)
   const T exu = dot_e<S, LAYOUT, q>(u);
-  const T two = T(2) * exu;
   const T b = div_cs<1>(exu);
   const T h = T(0.5) * (b * b);
+  // 2 e.u is exact, so one fused multiply-add IS the reference's "2 * exu - uxu" (two roundings of which the first
+  // does nothing): one instruction instead of two per population
+  const T two = T(2) * exu;
   const T aq = div_cs<0>(two - uxu);
   const T ao = div_cs<0>(-two - uxu);
   fq = T(S::W[q]) * (rho * (aq + h + T(1)));

@@ -372,7 +372,8 @@ def test_three_instruction_division_by_the_cs2_constants_is_the_ieee_quotient(tm
     src = os.path.join(ROOT, "tests", "aux", "exact_division_check.c")
     subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", src, "-o", str(exe), "-lm", "-lpthread"],
                    check=True)
-    for args in (["f32", "61"], ["f64", "40000000"]):
+    # f32two: the two-instruction fp32 form the kernels use since round 3 (x r_hi + RN(x r_lo))
+    for args in (["f32two", "61"], ["f32", "61"], ["f64", "40000000"]):
         out = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and out.stdout.strip() == "mismatches 0", (args, out.stdout, out.stderr)
 
