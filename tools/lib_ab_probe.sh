@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of builds of the engine library on the judged command: tools/lib_ab_probe.sh <tag> <other.so> [<other2.so> ...]
+# (separate processes: +- 3 % from clocks and page placement alone -- tools/same_buffer_ab.py compares in one process)
 TAG=$1; shift; OUT=gpurun_out/$TAG; mkdir -p $OUT
 line() { python - "$1" <<'PY'
 import json, sys
