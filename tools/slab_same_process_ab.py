@@ -1,6 +1,6 @@
 """The slab rehearsal (512 x 512 x 64, direct two-step schedule, halo messages through RCCL to the rank itself) with two
 builds of the engine library IN ONE PROCESS, batches alternating: ms per step each.  (Separate processes differ by
-+- 4 % through clocks and page placement alone.)   usage: slab_same_process_ab.py other.so"""
++- 4 % through clocks and page placement alone.)   usage: slab_same_process_ab.py other.so | ENV=value[,ENV=value] ..."""
 import sys, os, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29617")
@@ -16,12 +16,27 @@ ctx = lt.Context(device=torch.device("cuda", 0), dtype=torch.float32, use_native
 slab = lt.ZSlab([512, 512, 64])
 
 
-def build(path):
+def build(spec):
+    """spec: a library path, or "ENV=value,ENV2=value2" (driver switches read at construction), or "" = the product"""
     nat._LIB = None
+    path, env = (spec, {}) if "=" not in spec else ("", dict(kv.split("=", 1) for kv in spec.split(",")))
     if path:
         os.environ["LT_ENGINE_LIBRARY"] = path
     else:
         os.environ.pop("LT_ENGINE_LIBRARY", None)
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return _build()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _build():
     flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 1600, 0.1, lt.D3Q19(), slab=slab)
     sim = lt.TwoStepSlabSimulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab, transport="rccl", direct=True)
     sim(6)
