@@ -416,6 +416,22 @@ int lt_plan_last_run_info(lt_plan *plan, int64_t *single_step_launches, int64_t 
  * them): -1 = automatic (3, or 4 for fp32 KBC, once the populations stream from HBM and the launch
  * fills the chip several times over; no cap otherwise), 0 = no cap, 2..8 = that many. */
 int lt_plan_set_residency(lt_plan *plan, int32_t workgroups_per_cu);
+/* First-use check of the two-step kernels of a plan WITH masks.  Before such a plan uses a two-step kernel for the
+ * first time (lt_run's pairs, lt_resident_advance, every lt_stream_collide_twice* entry point,
+ * lt_plan_two_step_admitted), one double step over all its planes is held against two one-step launches: synthetic
+ * populations on engine-owned scratch buffers, the plan's own masks, boundaries, tile and segment length, bit-for-bit
+ * comparison on the device (four scratch fields, five launches, one synchronisation of an engine-owned stream; again
+ * after lt_plan_set_masks or a change of the segment length).  If the two disagree -- hipcc has miscompiled exactly
+ * this code once, see csrc/Makefile -- or the check cannot run, the plan keeps the one-step kernel: lt_run /
+ * lt_continue / lt_resident_advance fall back by themselves and leave the reason in lt_last_error(); the explicit
+ * two-step entry points and lt_plan_two_step_admitted return LT_ERR_UNSUPPORTED with it.  What is protected:
+ * lettuce/_simulation.py:177-189 (collision, then every boundary in index order, on the nodes of its mask).
+ * lt_plan_set_canary: 1 = check on first use (default), 0 = trust the kernel, 2 = report a mismatch without
+ * launching (test hook).  lt_plan_canary_status: 0 = not run yet, 1 = passed, 2 = skipped, -1 = failed (then
+ * *mismatches_out holds the number of differing populations, or 0 when the check could not run, and *message_out
+ * the reason; the string lives as long as the plan). */
+int lt_plan_set_canary(lt_plan *plan, int32_t mode);
+int lt_plan_canary_status(lt_plan *plan, int32_t *status_out, int64_t *mismatches_out, const char **message_out);
 
 #ifdef __cplusplus
 }

@@ -123,6 +123,8 @@ SYMBOLS = {
     "lt_stream_collide_many": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i32, _vp]),
     "lt_plan_set_many_step": (ctypes.c_int, [_vp, _i32]),
     "lt_probe_copy": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "lt_plan_set_canary": (ctypes.c_int, [_vp, _i32]),
+    "lt_plan_canary_status": (ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_char_p)]),
 }
 
 _LIB = None
@@ -231,6 +233,7 @@ class Plan:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self._keepalive = {}            # boundary index -> field tensor the engine holds a pointer to
+        self._const = {}                # answers of the engine that do not change while the masks stay
         self.pop_stride = 0             # elements between populations of the caller's buffers (0 = dense)
         desc = _PlanDesc()
         desc.abi_version = LT_ABI_VERSION
@@ -283,12 +286,32 @@ class Plan:
             raise NativeEngineError(f"tensor on {t.device}; the HIP engine needs device memory")
         if t.dtype != self.dtype:
             raise NativeEngineError(f"tensor dtype {t.dtype}, plan dtype {self.dtype}")
-        if not t.is_contiguous():
-            stride = getattr(self, "pop_stride", 0)
-            if not (stride and t.dim() > 1 and t.stride(0) == stride and t[0].is_contiguous()):
-                raise NativeEngineError("population tensors must be contiguous (or carry the plan's population stride)")
+        stride = getattr(self, "pop_stride", 0)
+        populations = shape is not None and list(shape) == list(self.f_shape)
+        if stride and populations:
+            # the engine addresses population q at q * stride: a dense clone() / empty_like() of a padded tensor
+            # would be written up to (q - 1) * pad elements past its end
+            if not (t.dim() > 1 and t.stride(0) == stride and t[0].is_contiguous()):
+                raise NativeEngineError(f"this plan's population buffers have {stride} elements between populations "
+                                        f"(set_population_stride); got strides {tuple(t.stride())} -- allocate with "
+                                        f"empty_populations() / populations_like()")
+        elif not t.is_contiguous():
+            raise NativeEngineError("population tensors must be contiguous (or carry the plan's population stride)")
         if shape is not None and list(t.shape) != list(shape):
             raise NativeEngineError(f"tensor shape {list(t.shape)}, expected {list(shape)}")
+
+    def _populations_ok(self, *tensors):
+        for t in tensors:
+            self._tensor_ok(t, self.f_shape)
+
+    def _message_ok(self, buf: Optional[torch.Tensor], blocks: int):
+        """a halo message buffer: `blocks` planes of n1 * n0 values, contiguous"""
+        if buf is None:
+            return
+        need = blocks * self.f_shape[-1] * self.f_shape[-2]
+        if buf.device.type != "cuda" or buf.dtype != self.dtype or not buf.is_contiguous() or buf.numel() < need:
+            raise NativeEngineError(f"halo message buffer: need a contiguous {self.dtype} device tensor of at least "
+                                    f"{need} elements, got {tuple(buf.shape)} {buf.dtype} on {buf.device}")
 
     @property
     def f_shape(self):
@@ -326,6 +349,7 @@ class Plan:
                 raise NativeEngineError(f"no_streaming_mask shape {list(nsm.shape)}, expected "
                                         f"{self.f_shape}")
         self._check(self.lib.lt_plan_set_masks(self._handle, _ptr(ncm), _ptr(nsm), _stream_handle()))
+        self._const.pop("blocks", None)
         # the compile kernel reads them asynchronously on the current stream
         if ncm is not None:
             ncm.record_stream(torch.cuda.current_stream())
@@ -361,42 +385,54 @@ class Plan:
 
     @_on_device
     def collide_planes(self, f, out, tau, begin, end):
+        self._populations_ok(f, out)
         self._check(self.lib.lt_collide_planes(self._handle, _ptr(f), _ptr(out), float(tau),
                                                int(begin), int(end), _stream_handle()))
 
     @_on_device
     def stream_planes(self, f, out, begin, end):
+        self._populations_ok(f, out)
         self._check(self.lib.lt_stream_planes(self._handle, _ptr(f), _ptr(out), int(begin),
                                               int(end), _stream_handle()))
 
     @_on_device
     def stream_collide_planes(self, f, out, tau, begin, end):
+        self._populations_ok(f, out)
         self._check(self.lib.lt_stream_collide_planes(self._handle, _ptr(f), _ptr(out), float(tau),
                                                       int(begin), int(end), _stream_handle()))
 
     def crossing(self, direction: int):
         """population indices whose velocity along the slowest memory axis is ``direction``"""
-        qs, n = (ctypes.c_int32 * 9)(), ctypes.c_int32()
-        self._check(self.lib.lt_slab_crossing(self._handle, int(direction), qs, ctypes.byref(n)))
-        return [int(qs[k]) for k in range(n.value)]
+        key = ("crossing", int(direction))
+        if key not in self._const:
+            qs, n = (ctypes.c_int32 * 9)(), ctypes.c_int32()
+            self._check(self.lib.lt_slab_crossing(self._handle, int(direction), qs, ctypes.byref(n)))
+            self._const[key] = [int(qs[k]) for k in range(n.value)]
+        return list(self._const[key])
 
     @_on_device
     def pack(self, f, plane, direction, buf):
+        self._populations_ok(f); self._message_ok(buf, len(self.crossing(direction)))
         self._check(self.lib.lt_slab_pack(self._handle, _ptr(f), int(plane), int(direction), _ptr(buf),
                                           _stream_handle()))
 
     @_on_device
     def unpack(self, f, plane, direction, buf):
+        self._populations_ok(f); self._message_ok(buf, len(self.crossing(direction)))
         self._check(self.lib.lt_slab_unpack(self._handle, _ptr(f), int(plane), int(direction), _ptr(buf),
                                             _stream_handle()))
 
     @_on_device
     def stream_collide_plane_pair(self, f, out, tau, first, second):
+        self._populations_ok(f, out)
         self._check(self.lib.lt_stream_collide_plane_pair(self._handle, _ptr(f), _ptr(out), float(tau),
                                                           int(first), int(second), _stream_handle()))
 
     @_on_device
     def stream_collide_plane_pair_packed(self, f, out, tau, first, second, pack_first, pack_second):
+        self._populations_ok(f, out)
+        for buf in (pack_first, pack_second):
+            self._message_ok(buf, len(self.crossing(1)))
         self._check(self.lib.lt_stream_collide_plane_pair_packed(
             self._handle, _ptr(f), _ptr(out), float(tau), int(first), int(second), _ptr(pack_first),
             _ptr(pack_second), _stream_handle()))
@@ -449,6 +485,7 @@ class Plan:
         """engine-owned padded buffers for the fused steps: -1 automatic, 0 off, 1 on"""
         self._check(self.lib.lt_plan_set_resident(self._handle, int(mode), int(pad_elements)))
 
+    @_on_device
     def resident_enabled(self):
         """(enabled, stride in elements of the resident buffers)"""
         on, stride = ctypes.c_int32(0), ctypes.c_int64(0)
@@ -561,6 +598,7 @@ class Plan:
                                                  ctypes.byref(blocks)))
         return {"vec": vec.value, "threads_per_block": tpb.value, "blocks": blocks.value}
 
+    @_on_device
     def kernel_name(self) -> str:
         return self.lib.lt_plan_kernel_name(self._handle).decode()
 
@@ -626,17 +664,24 @@ class Plan:
 
     @_on_device
     def stream_collide_twice_planes(self, f, out, tau, begin, end):
+        self._populations_ok(f, out)
         self._check(self.lib.lt_stream_collide_twice_planes(self._handle, _ptr(f), _ptr(out), float(tau),
                                                             int(begin), int(end), _stream_handle()))
 
     @_on_device
     def stream_collide_twice_planes_packed(self, f, out, tau, begin, end, pack_lower=None, pack_upper=None):
+        self._populations_ok(f, out)
+        for buf in (pack_lower, pack_upper):
+            self._message_ok(buf, self.two_step_message_blocks())
         self._check(self.lib.lt_stream_collide_twice_planes_packed(
             self._handle, _ptr(f), _ptr(out), float(tau), int(begin), int(end), _ptr(pack_lower),
             _ptr(pack_upper), _stream_handle()))
 
     @_on_device
     def stream_collide_twice_edges(self, f, out, tau, edge_planes, pack_lower=None, pack_upper=None):
+        self._populations_ok(f, out)
+        for buf in (pack_lower, pack_upper):
+            self._message_ok(buf, self.two_step_message_blocks())
         self._check(self.lib.lt_stream_collide_twice_edges(
             self._handle, _ptr(f), _ptr(out), float(tau), int(edge_planes), _ptr(pack_lower), _ptr(pack_upper),
             _stream_handle()))
@@ -645,6 +690,9 @@ class Plan:
     def stream_collide_twice_edges_direct(self, f, out, tau, edge_planes, recv_lower, recv_upper, pack_lower, pack_upper):
         """the two edges of the slab in one launch that reads the planes beyond the cuts from the received halo
         messages (no unpack) and writes both outgoing messages (no pack)"""
+        self._populations_ok(f, out)
+        for buf in (recv_lower, recv_upper, pack_lower, pack_upper):
+            self._message_ok(buf, self.two_step_message_blocks())
         self._check(self.lib.lt_stream_collide_twice_edges_direct(
             self._handle, _ptr(f), _ptr(out), float(tau), int(edge_planes), _ptr(recv_lower), _ptr(recv_upper),
             _ptr(pack_lower), _ptr(pack_upper), _stream_handle()))
@@ -653,6 +701,7 @@ class Plan:
     def stream_collide_twice_slab(self, f, out, tau):
         """all interior planes in one launch whose edge workgroups run first and count themselves done on a
         device counter (``wait_edges`` on another stream waits for it)"""
+        self._populations_ok(f, out)
         self._check(self.lib.lt_stream_collide_twice_slab(self._handle, _ptr(f), _ptr(out), float(tau), _stream_handle()))
 
     @_on_device
@@ -666,10 +715,13 @@ class Plan:
         return bool(flag.value)
 
     def two_step_message_blocks(self) -> int:
-        n = ctypes.c_int32(0)
-        self._check(self.lib.lt_slab_two_step_message_blocks(self._handle, ctypes.byref(n)))
-        return int(n.value)
+        if "blocks" not in self._const:            # depends on whether the plan has masks: set_masks forgets it
+            n = ctypes.c_int32(0)
+            self._check(self.lib.lt_slab_two_step_message_blocks(self._handle, ctypes.byref(n)))
+            self._const["blocks"] = int(n.value)
+        return self._const["blocks"]
 
+    @_on_device
     def two_step_admitted(self) -> Optional[str]:
         """None when the plan has a two-step launch; else the engine's reason"""
         if self.lib.lt_plan_two_step_admitted(self._handle) == 0:
@@ -678,11 +730,24 @@ class Plan:
 
     @_on_device
     def pack_two_step(self, f, side, buf):
+        self._populations_ok(f); self._message_ok(buf, self.two_step_message_blocks())
         self._check(self.lib.lt_slab_pack_two_step(self._handle, _ptr(f), int(side), _ptr(buf), _stream_handle()))
 
     @_on_device
     def unpack_two_step(self, f, side, buf):
+        self._populations_ok(f); self._message_ok(buf, self.two_step_message_blocks())
         self._check(self.lib.lt_slab_unpack_two_step(self._handle, _ptr(f), int(side), _ptr(buf), _stream_handle()))
+
+    def set_canary(self, mode: int = 1):
+        """first-use check of the masked two-step kernels: 1 = on (default), 0 = trust the kernel, 2 = report a
+        mismatch without launching (test hook)"""
+        self._check(self.lib.lt_plan_set_canary(self._handle, int(mode)))
+
+    def canary_status(self) -> dict:
+        """{"status": 0 not run / 1 passed / 2 skipped / -1 failed, "mismatches": n, "message": reason}"""
+        status, bad, msg = ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_char_p()
+        self._check(self.lib.lt_plan_canary_status(self._handle, ctypes.byref(status), ctypes.byref(bad), ctypes.byref(msg)))
+        return {"status": int(status.value), "mismatches": int(bad.value), "message": (msg.value or b"").decode("utf-8", "replace")}
 
     def set_residency(self, workgroups_per_cu: int = -1):
         """-1 automatic, 0 no cap, 2..8 workgroups resident per CU for the chip-filling launches"""

@@ -67,6 +67,27 @@ __global__ void __launch_bounds__(256) probe_copy_kernel(const probe_f4 *__restr
   }
 }
 
+// first-use check of the masked two-step kernels (run_canary): synthetic populations -- positive, near 1 / Q, a
+// different value in nearly every slot -- and a bit-for-bit comparison of two population fields over a plane range
+template <typename T>
+__global__ void __launch_bounds__(256) canary_fill_kernel(T *f, long long stride, long long N, int Q) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N * Q; i += (long long)gridDim.x * 256) {
+    const long long q = i / N, x = i - q * N;
+    const unsigned h = (unsigned)(((unsigned long long)i * 2654435761ull) >> 9) & 4095u;
+    f[q * stride + x] = (T)((1.0 / Q) * (1.0 + 0.2 * ((double)h / 4096.0 - 0.5)));
+  }
+}
+template <typename U>
+__global__ void __launch_bounds__(256) canary_compare_kernel(const U *a, const U *b, long long stride, long long first,
+                                                             long long count, int Q, unsigned long long *mismatches) {
+  unsigned long long mine = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count * Q; i += (long long)gridDim.x * 256) {
+    const long long q = i / count, x = first + (i - q * count);
+    mine += a[q * stride + x] != b[q * stride + x];
+  }
+  if (mine) atomicAdd(mismatches, mine);
+}
+
 }  // namespace
 
 struct lt_plan {
@@ -120,6 +141,13 @@ struct lt_plan {
   void *res[2] = {nullptr, nullptr};
   int res_cur = 0;
   int res_valid = 0;
+  // first-use check of the masked two-step kernel (run_canary; lt_plan_set_canary / lt_plan_canary_status)
+  int canary_mode = 1;       // 1 = check on first use, 0 = skip, 2 = test hook: report a mismatch without launching
+  int canary = 0;            // 0 = not run for the present masks / settings, 1 = passed, 2 = skipped, -1 = failed
+  int canary_running = 0;
+  long long canary_mismatches = 0;
+  char canary_msg[320] = "";
+  hipStream_t cstream = nullptr;
   char kernel_name[192];
   // launch-bound grids: a captured hipGraph of kGraphChunk fused steps (ping-pong returns to the
   // starting buffer), replayed on a plan-owned stream that is forked from / joined to the caller's
@@ -467,6 +495,7 @@ int masked_two_step_axis(const lt_plan *p) {
   return axis;
 }
 bool masked_two_step_ok(const lt_plan *p) { return masked_two_step_axis(p) >= 0; }
+bool canary_ok(lt_plan *p);
 
 int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long pb, long long pe,
          void *stream, long long stride = 1, void *pack_lo = nullptr, void *pack_hi = nullptr) {
@@ -493,6 +522,7 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
                                       "last plane of the slowest memory axis (periodic plans only) or at an end of "
                                       "the contiguous axis opposite a face of equilibrium nodes; no-streaming bits "
                                       "exactly that outlet's");
+    if (p->masked && !p->canary_running && !canary_ok(p)) return fail(LT_ERR_UNSUPPORTED, "%s", p->canary_msg);
   }
   if (p->desc.n_boundaries > 0 && !p->masked)
     return fail(LT_ERR_INVALID, "plan has boundaries but lt_plan_set_masks was not called");
@@ -643,6 +673,11 @@ bool two_step_possible(lt_plan *p, const char **why) {
     *why = "no two-step kernel for this lattice / dtype / collision";
     return false;
   }
+  // with boundaries: the kernel is held against two one-step launches once per plan and set of masks (run_canary)
+  if (p->masked && !p->canary_running && !canary_ok(p)) {
+    *why = p->canary_msg;
+    return false;
+  }
   return true;
 }
 
@@ -662,6 +697,117 @@ bool two_step_wanted(lt_plan *p) {
   if (p->masked && p->esize == 8 && p->unit.d == 3 && two_step_tile(p).rows == 4) return false;
   const long long bytes = 2ll * p->unit.q * p->N * p->esize;
   return bytes > (128ll << 20);
+}
+
+// ---- first-use canary of the masked two-step kernels -----------------------------------------------------------
+// The boundary dispatch of these kernels is the code hipcc has miscompiled before (Makefile header, DESIGN.md
+// section 6: a register copy dropped at the join of the equilibrium branch -- wrong populations on inlet / outlet
+// nodes of one instantiation, right everywhere else, and different from build to build).  The build no longer runs
+// the pass at fault, but a green test on one compiler build does not protect the next one: the FIRST time a plan
+// with masks is about to use a two-step kernel, one double step over all its planes is held against two one-step
+// launches -- synthetic populations on scratch buffers, the plan's own masks, boundary table, tile and segment
+// length, bit-for-bit comparison on the device.  A mismatch (or scratch memory that cannot be had) keeps the plan on
+// the one-step kernel: two_step_possible() then says why, lt_run falls back by itself and leaves the reason in
+// lt_last_error(), the explicit two-step entry points fail with it.  Run again after lt_plan_set_masks and after a
+// change of the segment length or tile variant.  Costs four scratch fields and five launches, once.
+// Reference semantics being protected: lettuce/_simulation.py:177-189 (collision, then the boundaries in index order).
+void canary_verdict(lt_plan *p, int verdict, long long mismatches, const char *fmt, ...) {
+  p->canary = verdict;
+  p->canary_mismatches = mismatches;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(p->canary_msg, sizeof p->canary_msg, fmt, ap);
+  va_end(ap);
+  if (verdict < 0) snprintf(g_error, sizeof g_error, "%s", p->canary_msg);
+}
+
+template <typename T, typename U>
+void run_canary(lt_plan *p) {
+  const int g = p->desc.ghost_planes;
+  if (g == 1) { canary_verdict(p, 2, 0, "no two-step launch on a plan with one ghost plane"); return; }
+  if (!p->cstream && hipStreamCreateWithFlags(&p->cstream, hipStreamNonBlocking) != hipSuccess) {
+    canary_verdict(p, -1, 0, "two steps per launch with boundaries: cannot create the canary's stream; the plan keeps "
+                             "the one-step kernel");
+    return;
+  }
+  const size_t bytes = (size_t)p->unit.q * p->N * p->esize;
+  void *buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned long long *count = nullptr;
+  bool ok = hipMalloc((void **)&count, sizeof *count) == hipSuccess;
+  for (void *&b : buf) ok = ok && hipMalloc(&b, bytes) == hipSuccess;
+  auto release = [&]() { for (void *b : buf) if (b) (void)hipFree(b); if (count) (void)hipFree(count); };
+  if (!ok) {
+    release();
+    canary_verdict(p, -1, 0, "two steps per launch with boundaries: no memory for the first-use check (4 x %zu "
+                             "bytes); the plan keeps the one-step kernel", bytes);
+    return;
+  }
+  // the plan as the caller set it up, but on dense scratch buffers and without the slab drivers' per-launch state
+  const long long s_in = p->stride_in_now, s_out = p->stride_out_now, sb = p->second_begin, se = p->second_end;
+  unsigned long long *const sig = p->signal_now;
+  const void *const glo = p->ghost_lo_now, *const ghi = p->ghost_hi_now;
+  p->stride_in_now = p->stride_out_now = p->N;
+  p->second_begin = p->second_end = 0;
+  p->signal_now = nullptr;
+  p->ghost_lo_now = p->ghost_hi_now = nullptr;
+  p->canary_running = 1;
+  char saved_error[sizeof g_error];
+  memcpy(saved_error, g_error, sizeof g_error);
+  const double tau = 0.8;
+  const long long b1 = g ? 1 : 0, e1 = g ? p->n2 - 1 : p->n2, b2 = g, e2 = p->n2 - g;
+  hipLaunchKernelGGL((canary_fill_kernel<T>), dim3(1024), dim3(256), 0, p->cstream, (T *)buf[0], p->N, p->N, p->unit.q);
+  if (g) for (int i = 1; i < 4; ++i) (void)hipMemsetAsync(buf[i], 0, bytes, p->cstream);   // planes a slab launch never writes
+  (void)hipMemsetAsync(count, 0, sizeof *count, p->cstream);
+  int rc = step(p, lt::kFused, buf[0], buf[1], tau, b1, e1, p->cstream);
+  if (rc == LT_OK) rc = step(p, lt::kFused, buf[1], buf[2], tau, b2, e2, p->cstream);
+  if (rc == LT_OK) rc = step(p, lt::kFusedTwice, buf[0], buf[3], tau, b2, e2, p->cstream);
+  unsigned long long bad = 0;
+  hipError_t e = hipSuccess;
+  if (rc == LT_OK) {
+    const long long plane = (long long)p->n0 * p->n1;
+    hipLaunchKernelGGL((canary_compare_kernel<U>), dim3(1024), dim3(256), 0, p->cstream, (const U *)buf[2],
+                       (const U *)buf[3], p->N, plane * b2, plane * (e2 - b2), p->unit.q, count);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, count, sizeof bad, hipMemcpyDeviceToHost, p->cstream);
+  }
+  const hipError_t es = hipStreamSynchronize(p->cstream);
+  if (e == hipSuccess) e = es;
+  p->canary_running = 0;
+  p->stride_in_now = s_in; p->stride_out_now = s_out;
+  p->second_begin = sb; p->second_end = se;
+  p->signal_now = sig;
+  p->ghost_lo_now = glo; p->ghost_hi_now = ghi;
+  release();
+  if (rc != LT_OK) {
+    char why[sizeof g_error];
+    memcpy(why, g_error, sizeof why);
+    canary_verdict(p, -1, 0, "two steps per launch with boundaries: the first-use check could not run (%.160s); the "
+                             "plan keeps the one-step kernel", why);
+  } else if (e != hipSuccess) {
+    canary_verdict(p, -1, 0, "two steps per launch with boundaries: the first-use check failed with a HIP error (%s); "
+                             "the plan keeps the one-step kernel", hipGetErrorString(e));
+  } else if (bad != 0) {
+    canary_verdict(p, -1, (long long)bad, "two steps per launch with boundaries: the two-step kernel disagrees with two "
+                   "one-step launches in %llu of %lld populations (first-use check on this plan's masks); the plan "
+                   "keeps the one-step kernel", bad, (long long)p->unit.q * p->n0 * p->n1 * (e2 - b2));
+  } else {
+    memcpy(g_error, saved_error, sizeof g_error);
+    canary_verdict(p, 1, 0, "");
+  }
+}
+
+// may this plan's masked two-step kernel be used?  Runs the check if it has not been run for the present masks
+bool canary_ok(lt_plan *p) {
+  if (!p->masked) return true;
+  if (p->canary == 0) {
+    if (p->canary_mode == 0) canary_verdict(p, 2, 0, "");
+    else if (p->canary_mode == 2)
+      canary_verdict(p, -1, -1, "two steps per launch with boundaries: first-use check forced to fail "
+                                "(lt_plan_set_canary(plan, 2)); the plan keeps the one-step kernel");
+    else if (p->esize == 4) run_canary<float, unsigned>(p);
+    else run_canary<double, unsigned long long>(p);
+  }
+  return p->canary > 0;
 }
 
 constexpr int kManyMax = 8;        // == kManyMax of unit.inc
@@ -918,6 +1064,7 @@ int lt_plan_destroy(lt_plan *p) {
   if (p->gev_in) (void)hipEventDestroy(p->gev_in);
   if (p->gev_out) (void)hipEventDestroy(p->gev_out);
   if (p->gstream) (void)hipStreamDestroy(p->gstream);
+  if (p->cstream) (void)hipStreamDestroy(p->cstream);
   delete p;
   return LT_OK;
 }
@@ -967,6 +1114,7 @@ int lt_plan_set_masks(lt_plan *p, const uint8_t *ncm, const uint8_t *nsm, void *
   p->nsm_confined = (flags & 1u) == 0;
   p->inlet_faces_outlet = (flags & 2u) == 0;
   p->masked = 1;
+  p->canary = 0;                                     // new masks: the first-use check runs again
   return LT_OK;
 }
 
@@ -1138,6 +1286,7 @@ int lt_probe_copy(void *dst, const void *src, int64_t n_bytes, int32_t cache_pol
 int lt_plan_set_shift_policy(lt_plan *p, int32_t policy) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (policy < 0 || policy > 5) return fail(LT_ERR_INVALID, "shift policy %d", policy);
+  if (p->shift != policy) p->canary = 0;
   p->shift = policy;
   return LT_OK;
 }
@@ -1427,8 +1576,24 @@ int lt_plan_set_two_step(lt_plan *p, int32_t mode, int32_t planes_per_workgroup)
   if (planes_per_workgroup < 0 ||
       (planes_per_workgroup > 0 && !p->desc.ghost_planes && sweep % planes_per_workgroup != 0))
     return fail(LT_ERR_INVALID, "planes per workgroup %d does not divide %d", planes_per_workgroup, sweep);
+  if (p->seg_len != planes_per_workgroup) p->canary = 0;   // another segment length takes other paths of the sweep
   p->two_step = mode;
   p->seg_len = planes_per_workgroup;
+  return LT_OK;
+}
+
+int lt_plan_set_canary(lt_plan *p, int32_t mode) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (mode < 0 || mode > 2) return fail(LT_ERR_INVALID, "canary mode %d (0 skip, 1 check on first use, 2 report a mismatch)", mode);
+  if (mode != p->canary_mode) p->canary = 0;
+  p->canary_mode = mode;
+  return LT_OK;
+}
+int lt_plan_canary_status(lt_plan *p, int32_t *status, int64_t *mismatches, const char **message) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (status) *status = p->canary;
+  if (mismatches) *mismatches = p->canary_mismatches;
+  if (message) *message = p->canary_msg;
   return LT_OK;
 }
 

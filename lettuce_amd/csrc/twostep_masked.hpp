@@ -127,19 +127,6 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   // 105 KB -- and measured SLOWER (Obstacle D3Q27 256^3 BGK: 0.520 against 0.49 ms per update on the same box), so
   // the instruction cache is not what holds this kernel back; kept as a switch for the record.
   constexpr bool COMPACT = false;
-  // ONE_ROLE: all waves run ONE copy of the sweep with the output phase behind a scalar test, instead of one copy per
-  // wave role (below).  Used for D3Q27 in the slab layout, where the two-copy form returns wrong populations: in the
-  // copy of the waves that hold only intermediate nodes the FIRST plane of a segment gets wrong values on inlet
-  // nodes (BGK only; streaming alone is exact; the same source was right when built in round 2, and three differently
-  // compiled variants of round 3 were wrong in the same nodes with different values).  With one
-  // copy the kernel is bit-identical to two one-step launches again
-  // (test_obstacle_on_slabs_with_two_updates_per_launch[4-...-D3Q27]).  The other instantiations keep the two-copy
-  // form, which their bit-identity tests cover (random masks, inlet faces, the reference's Obstacle vectors) and which
-  // is the faster one: Obstacle D3Q27 256^3 BGK in the reference layout 0.48-0.49 against 0.514 ms per update.
-#ifndef LT_FORCE_TWO_ROLES
-#define LT_FORCE_TWO_ROLES 0      // 1: the two-copy form everywhere (reproduces the defect: tools/debug_obst27b.py)
-#endif
-  constexpr bool ONE_ROLE = S::Q >= 27 && LAYOUT == 1 && !LT_FORCE_TWO_ROLES;
   __shared__ T lds_u[4][NU][NI];
   __shared__ T lds_c[3][NC][NI];
   __shared__ T lds_d[3][ND][NI];
@@ -416,7 +403,7 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
       load_a(s);     compute_a(1, 1, s);
       load_a(s + 1); compute_a(2, 2, s + 1);
     }
-    if constexpr (HAS_B) { if (!ONE_ROLE || b_wave) nd_b_next = p.node[(unsigned)s * plane_nodes + b_own]; }
+    if constexpr (HAS_B) nd_b_next = p.node[(unsigned)s * plane_nodes + b_own];
     if (s + 2 <= last) load_a(s + 2);
     int r = 1, r3 = 1;                              // output plane k has relative index k - s + 1
     // one barrier interval: B(k) and, while planes are left, A(k + 2) and the loads of plane k + 3.
@@ -426,18 +413,16 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
       const bool do_a = FULL || k + 2 <= last, do_l = FULL || k + 3 <= last;
       lds_barrier();                                // planes up to k + 1 complete; reads of k - 1 done
       if constexpr (HAS_B) {
-        if (!ONE_ROLE || b_wave) {
-          nd_b = nd_b_next;
-          read_b(r, r3, k);                         // the LDS reads are in flight behind the collide of A
-        }
+        nd_b = nd_b_next;
+        read_b(r, r3, k);                           // the LDS reads are in flight behind the collide of A
       }
       if (do_a) compute_a(r + 2, r3 == 0 ? 2 : r3 - 1, k + 2);     // (r + 2) % 3
       if constexpr (HAS_B) {
         // fetched ahead and in front of the population loads: waiting for it never waits for a store
-        if ((!ONE_ROLE || b_wave) && (FULL || k + 1 < last)) nd_b_next = p.node[(unsigned)(k + 1) * plane_nodes + b_own];
+        if (FULL || k + 1 < last) nd_b_next = p.node[(unsigned)(k + 1) * plane_nodes + b_own];
       }
       if (do_a && do_l) load_a(k + 3);
-      if constexpr (HAS_B) { if (!ONE_ROLE || b_wave) finish_b(k); }
+      if constexpr (HAS_B) finish_b(k);
       ++r;
       r3 = r3 == 2 ? 0 : r3 + 1;
     };
@@ -453,12 +438,8 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   };
 
   // roles are uniform per wave: branch on a scalar register
-  if constexpr (ONE_ROLE) {
-    sweep(std::true_type{});
-  } else {
-    if (!b_wave) sweep(std::false_type{});
-    else sweep(std::true_type{});
-  }
+  if (!b_wave) sweep(std::false_type{});
+  else sweep(std::true_type{});
 }
 
 }  // namespace lt

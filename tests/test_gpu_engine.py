@@ -636,6 +636,134 @@ def _check_masked_two_step(plan, f0, refused, res, seg, name="lbm2m_kernel"):
     np.testing.assert_array_equal(c.cpu().numpy(), b.cpu().numpy())
 
 
+# ---- the same in the SLAB layout (z slowest, two ghost planes): what a multi-GPU rank runs.  Round 4: these are the
+# instantiations in which hipcc dropped register copies at the join of the equilibrium branch (csrc/Makefile header,
+# DESIGN.md section 6); until then only the Obstacle on slabs exercised them.
+def _masked_slab_case(lat, res, dtype, outlet, seed, with_field=False, abb_first=False):
+    """Random bounce-back / equilibrium nodes in the memory order of a slab-layout plan ([z + 4, y, x]) plus,
+    optionally, an anti-bounce-back outlet at x = nx - 1 (side +1) or x = 0 (side -1) with the face opposite it an
+    inlet of equilibrium nodes -- the masks lettuce's Obstacle builds on a z-slab (obstacle.py:108-122,
+    anti_bounce_back_outlet.py:93-103)."""
+    L = orc.LATTICES[lat]
+    nx, ny, nz = res
+    shape = [nz + 4, ny, nx]
+    g = torch.Generator().manual_seed(seed)
+    e, w = orc.lattice_tensors(L, dtype)
+    f0 = (torch.tensor(L.w, dtype=torch.float64).reshape(-1, 1, 1, 1)
+          * (1 + 0.2 * torch.rand([L.q] + shape, generator=g, dtype=torch.float64))).to(dtype)
+    bb_mask = torch.rand(shape, generator=g) < 0.2
+    eq_mask = (torch.rand(shape, generator=g) < 0.15) & ~bb_mask
+    units = orc.Units(10, 0.1)
+    vel = torch.tensor([0.2, 0.1, -0.3], dtype=dtype)
+    feq = orc.quadratic_equilibrium(units.pressure_pu_to_density_lu(torch.tensor(0.01, dtype=dtype)),
+                                    units.velocity_to_lu(vel), e, w)
+    entries = [{"kind": "bounce_back"}, {"kind": "equilibrium", "feq": feq.double().tolist()}]
+    if with_field:
+        field = (feq.reshape(-1, 1, 1, 1) * (1 + 0.1 * torch.rand([L.q] + shape, generator=g, dtype=torch.float64))).to(dtype)
+        entries[1] = {"kind": "equilibrium", "field": field.cuda()}
+    ncm = torch.zeros(shape, dtype=torch.uint8)
+    nsm = torch.zeros([L.q] + shape, dtype=torch.uint8)
+    out_mask = None
+    if outlet is not None:
+        xo, xi = (nx - 1, 0) if outlet == 1 else (0, nx - 1)
+        eq_mask[:, :, xi] = True
+        bb_mask[:, :, xi] = False
+        out_mask = torch.zeros(shape, dtype=torch.bool)
+        out_mask[:, :, xo] = True
+        for q in range(L.q):
+            if L.e[q][0] == -outlet:                       # the populations entering through the outlet are not streamed
+                nsm[q, :, :, xo] = 1
+        entry = {"kind": "abb_outlet", "axis": 0, "side": outlet}
+        entries = [entry] + entries if abb_first else entries + [entry]
+    for index, e_ in enumerate(entries, start=1):
+        ncm[{"bounce_back": bb_mask, "equilibrium": eq_mask}.get(e_["kind"], out_mask)] = index
+    return f0, ncm, nsm, entries
+
+
+MASKED_SLAB = [("D3Q19", [64, 16, 10], "f32"), ("D3Q27", [64, 8, 9], "f32"), ("D3Q15", [128, 8, 8], "f32"),
+               ("D3Q15", [32, 16, 7], "f64"), ("D3Q19", [32, 8, 8], "f64")]
+
+
+@pytest.mark.parametrize("lat,res,dt", MASKED_SLAB, ids=[f"{t[0]}-{'x'.join(map(str, t[1]))}-{t[2]}" for t in MASKED_SLAB])
+@pytest.mark.parametrize("outlet", [None, 1, -1])
+@pytest.mark.parametrize("coll", ["bgk", "none"])
+@pytest.mark.parametrize("seg", [0, 2, 3])
+def test_masked_two_step_in_the_slab_layout_is_bit_identical_to_two_masked_single_steps(lat, res, dt, outlet, coll, seg):
+    """lbm2m_kernel<..., LAYOUT 1, ...> on a plan with two ghost planes: random bounce-back and equilibrium nodes
+    (table / per-node field), with and without the Obstacle's outlet along the contiguous axis x (either end), BGK
+    and streaming only, every segment length: one launch over the interior planes == two masked one-step launches,
+    bit for bit; and the plan's first-use check has run and passed."""
+    from lettuce_amd._native import Plan, LAYOUT_SLAB
+    dtype = TORCH_DT[dt]
+    f0, ncm, nsm, entries = _masked_slab_case(lat, res, dtype, outlet, 71, with_field=(seg == 3), abb_first=(seg == 2))
+    plan = Plan(lat, dtype, coll, res, entries, layout=LAYOUT_SLAB, ghost_planes=2)
+    plan.set_masks(dev(ncm), dev(nsm))
+    f = dev(f0)
+    a, b, c = torch.zeros_like(f), torch.zeros_like(f), torch.full_like(f, float("nan"))
+    n2 = f.shape[1]
+    plan.stream_collide_planes(f, a, 0.7, 1, n2 - 1)
+    plan.stream_collide_planes(a, b, 0.7, 2, n2 - 2)
+    plan.set_two_step(1, seg)
+    assert plan.canary_status()["status"] == 0
+    plan.stream_collide_twice_planes(f, c, 0.7, 2, n2 - 2)
+    torch.cuda.synchronize()
+    assert "lbm2m_kernel" in plan.kernel_name() and ", 1, " in plan.kernel_name()
+    assert plan.canary_status() == {"status": 1, "mismatches": 0, "message": ""}
+    np.testing.assert_array_equal(c[:, 2:n2 - 2].cpu().numpy(), b[:, 2:n2 - 2].cpu().numpy())
+
+
+def test_first_use_check_of_the_masked_two_step_kernel_and_its_fallback():
+    """Every plan with masks holds its two-step kernel against two one-step launches before it uses it
+    (lt_plan_set_canary, include/lettuce_hip.h).  A plan whose check fails (forced here) keeps the one-step kernel:
+    lt_run gives the one-step result and says why in lt_last_error, the explicit entry points refuse."""
+    from lettuce_amd._native import NativeEngineError
+    dtype = torch.float32
+    res = [6, 8, 64]
+    f0, ncm, nsm, entries = _masked_case("D3Q19", res, dtype, (0, 1), 5)
+    tau = 0.7
+
+    def plan_with(mode):
+        plan = plan_for("D3Q19", dtype, "bgk", res, entries)
+        plan.set_masks(dev(ncm), dev(nsm))
+        plan.set_resident(0)
+        plan.set_canary(mode)
+        plan.set_two_step(1, 0)
+        return plan
+
+    one = plan_with(1)
+    one.set_two_step(0)
+    want = run_engine(one, f0, tau, 7)
+    assert one.last_run_info()["two_step_launches"] == 0 and one.canary_status()["status"] == 0    # never needed
+
+    checked = plan_with(1)
+    np.testing.assert_array_equal(run_engine(checked, f0, tau, 7), want)
+    assert checked.last_run_info()["two_step_launches"] == 3
+    assert checked.canary_status() == {"status": 1, "mismatches": 0, "message": ""}
+    checked.set_masks(dev(ncm), dev(nsm))                     # new masks: checked again at the next use
+    assert checked.canary_status()["status"] == 0
+    assert "lbm2m_kernel" in checked.kernel_name() and checked.canary_status()["status"] == 1
+
+    trusted = plan_with(0)
+    np.testing.assert_array_equal(run_engine(trusted, f0, tau, 7), want)
+    assert trusted.last_run_info()["two_step_launches"] == 3 and trusted.canary_status()["status"] == 2
+
+    failed = plan_with(2)
+    np.testing.assert_array_equal(run_engine(failed, f0, tau, 7), want)       # the one-step kernel did the work
+    info = failed.last_run_info()
+    assert info["two_step_launches"] == 0 and info["single_step_launches"] == 6
+    status = failed.canary_status()
+    assert status["status"] == -1 and "first-use check" in status["message"] and "one-step kernel" in status["message"]
+    assert "first-use check" in failed.lib.lt_last_error().decode()
+    assert "lbm2m_kernel" not in failed.kernel_name() and "lbm_kernel" in failed.kernel_name()
+    assert "first-use check" in failed.two_step_admitted()
+    f = dev(f0)
+    with pytest.raises(NativeEngineError, match="first-use check"):
+        failed.stream_collide_twice(f, torch.empty_like(f), tau)
+    failed.set_canary(1)                                       # checked for real now
+    np.testing.assert_array_equal(run_engine(failed, f0, tau, 7), want)
+    assert failed.last_run_info()["two_step_launches"] == 3 and failed.canary_status()["status"] == 1
+
+
 def test_masked_two_step_is_refused_when_no_streaming_bits_lie_off_the_outlet_plane():
     """The admission test of the masked two-step kernel runs on the device when the masks are compiled."""
     f0, ncm, nsm, entries = _masked_case("D3Q19", [4, 8, 64], torch.float32, (0, 1), 3)

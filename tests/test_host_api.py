@@ -378,6 +378,79 @@ def test_three_instruction_division_by_the_cs2_constants_is_the_ieee_quotient(tm
         assert out.returncode == 0 and out.stdout.strip() == "mismatches 0", (args, out.stdout, out.stderr)
 
 
+def test_masked_two_step_isa_has_no_dropped_register_copies(tmp_path):
+    """Round 3's wrong result was hipcc dropping three register copies at the join of the equilibrium branch of
+    lbm2m_kernel<float, D3Q27, slab, BGK, 64 x 4, AX = 0> (SIOptimizeVGPRLiveRange marks their source <undef>; the ISA
+    then reads "; kill: def $vgprA killed $vgprB").  The product build switches that pass off (csrc/Makefile); this
+    compiles that one kernel with the Makefile's flags -- device side only, ~10 s -- and looks for the pattern
+    (`make -C lettuce_amd/csrc isa-check` does the same for every unit)."""
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "lettuce_amd", "csrc")
+    makefile = open(os.path.join(csrc, "Makefile")).read()
+    flags = re.search(r"^CXXFLAGS\s*=\s*(.*?)(?<!\\)$", makefile, re.M | re.S).group(1).replace("\\\n", " ").split()
+    assert "-amdgpu-opt-vgpr-liverange=false" in flags, flags
+    flags = [f.replace("$(ARCH)", "gfx950").replace("-I../../include", "-I" + os.path.join(ROOT, "include")) for f in flags]
+    out = tmp_path / "masked_two_step.s"
+    subprocess.run([hipcc] + flags + ["-I" + csrc, "-S", "--cuda-device-only", os.path.join(ROOT, "tests", "aux", "masked_two_step_isa.hip"),
+                    "-o", str(out)], check=True, capture_output=True, timeout=600)
+    isa = out.read_text()
+    assert "lbm2m_kernel" in isa and "ds_bpermute_b32" in isa          # the kernel is there, outlet along the rows
+    dropped = re.findall(r"kill: def \$[sv]gpr\d+ killed \$[sv]gpr\d+ ", isa)
+    assert dropped == [], dropped
+
+
+def test_a_plan_with_a_population_stride_refuses_dense_tensors():
+    """with a population stride set, the engine addresses population q at q * stride; a dense
+    clone() / empty_like() of a padded tensor handed to ANY entry point would be written past its end.  The checks
+    of the binding run before the library is touched, so a CPU-side stand-in for the tensors shows them."""
+    from lettuce_amd import _native
+
+    class FakePlan(_native.Plan):
+        def __init__(self):                                   # no library, no device
+            self.dtype, self.q, self.d = torch.float32, 19, 3
+            self.resolution, self.layout, self.ghost_planes = [8, 4, 6], _native.LAYOUT_SLAB, 2
+            self.pop_stride, self._handle, self._const = 8 * 4 * 10 + 64, None, {"blocks": 19, ("crossing", 1): [5, 7, 10, 11, 14]}
+
+    class OnDevice:                                           # a meta tensor that claims to live on the GPU
+        def __init__(self, t):
+            self.t = t
+        device = torch.device("cuda", 0)
+        def __getattr__(self, name):
+            return getattr(self.t, name)
+        def __getitem__(self, i):
+            return OnDevice(self.t[i])
+
+    plan = FakePlan()
+    shape = plan.f_shape
+    dense = OnDevice(torch.empty(shape, device="meta"))
+    inner = torch.empty(shape[1:], device="meta").stride()
+    padded = OnDevice(torch.empty(plan.q * plan.pop_stride, device="meta").as_strided(shape, (plan.pop_stride,) + tuple(inner)))
+    plan._tensor_ok(padded, shape)
+    plan._populations_ok(padded, padded)
+    with pytest.raises(_native.NativeEngineError, match="elements between populations"):
+        plan._tensor_ok(dense, shape)
+    with pytest.raises(_native.NativeEngineError, match="elements between populations"):
+        plan._populations_ok(padded, dense)
+    plan._tensor_ok(OnDevice(torch.empty(shape[1:], device="meta")), shape[1:])      # per-node fields stay dense
+    small = OnDevice(torch.empty([18, 4, 8], device="meta"))
+    with pytest.raises(_native.NativeEngineError, match="halo message buffer"):
+        plan._message_ok(small, plan.two_step_message_blocks())
+    plan._message_ok(OnDevice(torch.empty([19, 4, 8], device="meta")), plan.two_step_message_blocks())
+    # every slab entry point of the binding checks its population arguments
+    import inspect
+    unchecked = [name for name in ("collide_planes", "stream_planes", "stream_collide_planes", "stream_collide_plane_pair",
+                                   "stream_collide_plane_pair_packed", "stream_collide_twice_planes",
+                                   "stream_collide_twice_planes_packed", "stream_collide_twice_edges",
+                                   "stream_collide_twice_edges_direct", "stream_collide_twice_slab", "pack", "unpack",
+                                   "pack_two_step", "unpack_two_step")
+                 if "_populations_ok(" not in inspect.getsource(inspect.unwrap(getattr(_native.Plan, name)))]
+    assert unchecked == [], unchecked
+
+
 def test_bench_finds_the_committed_pmc_traffic_for_the_fused_kernel(monkeypatch):
     """bench.py fills roofline.traffic from profiles/traffic.json by kernel name -- the name the engine
     reports (lt_plan_kernel_name) and the one rocprofv3 prints differ in case and suffix -- and only when
