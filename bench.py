@@ -107,10 +107,12 @@ def parse(argv=None):
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the untimed re-run with the one-step kernel (profiling passes)")
     ap.add_argument("--no-overlap", action="store_true", help="slab path: exchange without overlap")
-    ap.add_argument("--transport", choices=["auto", "all", "rccl", "window"],
+    ap.add_argument("--transport", choices=["auto", "all", "rccl", "window", "copy"],
                     default=os.environ.get("LT_BENCH_TRANSPORT", "auto"),
-                    help="slab path: ghost-plane transport (lettuce_amd/_slab.py).  auto = RCCL send/recv only "
-                         "(both slab drivers; results must be bit-identical); all = also the launch that signals the "
+                    help="slab path: ghost-plane transport (lettuce_amd/_slab.py).  auto = RCCL send/recv (both slab "
+                         "drivers) and, for the two-step driver, the copy-engine transport (no RCCL kernel beside the sweep; "
+                         "a lost message is a time-out the driver raises, not a trap); results must be bit-identical; "
+                         "all = also the launch that signals the "
                          "exchange from inside and the one-sided peer-window transports, which are faster in "
                          "the one-GPU rehearsal but have never run across real xGMI links and end in a device "
                          "trap if a signal is lost -- opt in with --transport all or LT_BENCH_TRANSPORT=all")
@@ -672,7 +674,7 @@ def slab_bench(args, lt, dist, world, rank, local_rank, device):
                                             transport=transport.split("-")[0],
                                             fused_remote_pack=transport.endswith("-fused"),
                                             signalled=transport.endswith("-signalled"),
-                                            direct=transport == "rccl")
+                                            direct=transport in ("rccl", "copy"))
         return lt.SlabSimulation(flow, coll, slab, overlap=not args.no_overlap, transport=transport)
 
     # Candidates: slab driver (two lattice updates per launch and one halo exchange per two updates / one update per
@@ -681,6 +683,12 @@ def slab_bench(args, lt, dist, world, rank, local_rank, device):
     transports = {"auto": ["rccl"], "all": ["rccl", "window"]}.get(args.transport, [args.transport])
     drivers = ["two-step", "single-step"] if args.driver == "auto" else [args.driver]
     wanted = [(d, t) for d in drivers for t in transports]
+    if args.transport in ("auto", "all") and "two-step" in drivers and not args.no_overlap:
+        # the direct schedule with the halo messages moved by copy engines into windows the neighbours mapped
+        # (lettuce_amd/_slab.py, _CopyWindow): no RCCL kernel beside the sweep.  A candidate like the others: it must be
+        # bit-identical to single-step/rccl twice and faster than the held line; a message that does not arrive ends in
+        # a time-out the driver raises after the batch (nothing traps), i.e. in config.transport.failures
+        wanted.insert(wanted.index(("two-step", "rccl")) + 1, ("two-step", "copy"))
     if args.transport == "all" and "two-step" in drivers and not args.no_overlap:
         at = wanted.index(("two-step", "rccl")) + 1
         wanted[at:at] = [("two-step", "rccl-edges"), ("two-step", "rccl-signalled")]
@@ -725,9 +733,11 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
         how = {"rccl": "RCCL send/recv of the halo messages",
                "rccl-edges": "RCCL send/recv ghost planes; edge launches, pack and unpack beside the interior launch",
                "rccl-signalled": "RCCL send/recv ghost planes, released by the edge workgroups of the one launch per double step",
+               "copy": "halo messages moved by device-to-device copies without compute units (copy engines) into receive "
+                       "windows the neighbours mapped through HIP IPC, arrival counters written in stream order",
                }.get(transport, "one-sided ghost-plane stores into peer windows (xGMI peer access)"
                      + (", issued by the edge launches" if transport.endswith("-fused") else ""))
-        if driver == "two-step" and transport == "rccl":
+        if driver == "two-step" and transport in ("rccl", "copy"):
             how += (" straight out of / into the buffers the edge launch writes / reads (no pack, no unpack); edge launch, "
                     "then the planes in between, on one stream")
         how += ("; two lattice updates per launch, one exchange per two updates" if driver == "two-step"
@@ -891,6 +901,8 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
             kernel = cand.engine.kernel_name() if hasattr(cand.engine, "kernel_name") else type(cand.engine).__name__
             line = make_line(name, driver, transport, batch_s, repeat, kernel, verified)
             line["config"]["transport"]["rank_checksums"] = sums
+            if getattr(cand, "_cw", None) is not None:
+                line["config"]["transport"]["copy_engine"] = sorted(cand._cw.engines_used)
             if held.line is None or line["value"] > held.line["value"]:
                 held.line = line
             else:

@@ -433,6 +433,27 @@ int lt_plan_set_residency(lt_plan *plan, int32_t workgroups_per_cu);
 int lt_plan_set_canary(lt_plan *plan, int32_t mode);
 int lt_plan_canary_status(lt_plan *plan, int32_t *status_out, int64_t *mismatches_out, const char **message_out);
 
+/* Halo transport without compute units (slab drivers, transport "copy"; SURVEY.md 8(e): the reference has no
+ * multi-GPU path, north_star asks for send/recv over xGMI overlapped with the interior).  RCCL moves a message with a
+ * kernel of 64 workgroups and 20 KB of LDS each, which cannot share a compute unit with a 150 KB sweep workgroup and
+ * costs the sweep beside it about 5 %; a device-to-device copy handed to a copy (SDMA) engine needs neither.
+ *   lt_ipc_alloc / lt_ipc_open / lt_ipc_close / lt_ipc_free   device memory the other processes of the node can map:
+ *       every rank allocates its receive window (halo messages + one 64-bit arrival counter per direction), sends the
+ *       64-byte handle to its two z-neighbours through the process group and opens theirs;
+ *   lt_halo_copy   dst <- src on `stream`; engine 1 = without compute units (hipMemcpyDeviceToDeviceNoCU: an SDMA
+ *       engine, over xGMI when dst is a neighbour's window), 0 = the runtime's choice; *engine_used reports which;
+ *   lt_flag_write  *flag <- value in stream order after the copies: how 1 = stream memory operation (command
+ *       processor, no kernel), 0 = a one-thread kernel storing at system scope;
+ *   lt_flag_wait   one wave that returns when *flag >= at_least or, after about a second, sets *timed_out_dev and
+ *       returns all the same (the driver raises at the end of the batch; nothing traps, nothing spins for ever). */
+int lt_ipc_alloc(int64_t n_bytes, void **dev_out, void *handle_out_64_bytes);
+int lt_ipc_open(const void *handle_64_bytes, void **dev_out);
+int lt_ipc_close(void *mapped_dev);
+int lt_ipc_free(void *dev);
+int lt_halo_copy(void *dst_dev, const void *src_dev, int64_t n_bytes, int32_t engine, void *stream, int32_t *engine_used);
+int lt_flag_write(uint64_t *flag_dev, uint64_t value, int32_t how, void *stream);
+int lt_flag_wait(const uint64_t *flag_dev, uint64_t at_least, uint32_t *timed_out_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

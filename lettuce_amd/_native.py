@@ -123,6 +123,13 @@ SYMBOLS = {
     "lt_stream_collide_many": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i32, _vp]),
     "lt_plan_set_many_step": (ctypes.c_int, [_vp, _i32]),
     "lt_probe_copy": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "lt_ipc_alloc": (ctypes.c_int, [_i64, ctypes.POINTER(_vp), ctypes.c_char_p]),
+    "lt_ipc_open": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_vp)]),
+    "lt_ipc_close": (ctypes.c_int, [_vp]),
+    "lt_ipc_free": (ctypes.c_int, [_vp]),
+    "lt_halo_copy": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, ctypes.POINTER(_i32)]),
+    "lt_flag_write": (ctypes.c_int, [_vp, ctypes.c_uint64, _i32, _vp]),
+    "lt_flag_wait": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp, _vp]),
     "lt_plan_set_canary": (ctypes.c_int, [_vp, _i32]),
     "lt_plan_canary_status": (ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_char_p)]),
 }

@@ -13,6 +13,10 @@ that computes the plane.
 Transports (``transport=``):
   "rccl"    batched isend/irecv through the process group (RCCL point-to-point over xGMI; gloo in
             the CPU tests).  The default.
+  "copy"    the halo messages travel by device-to-device copies that use no compute unit (SDMA engines over xGMI)
+            into receive windows the neighbours mapped through HIP IPC; arrival is a counter word written in stream
+            order behind the copy and polled by one wave on the receiver (``_CopyWindow``).  Nothing of it needs
+            LDS or a workgroup slot beside the sweep.
   "window"  one-sided: every rank exposes a receive window (torch symmetric memory: peer-mapped
             device memory + signal pads); the boundary-plane launch stores the crossing
             populations straight into the neighbours' windows over xGMI, a signal follows, the
@@ -103,6 +107,20 @@ def _comm_stream(device, priority):
     return _COMM_STREAMS[key]
 
 
+def _copy_streams(device, n):
+    """the streams the copy transport issues its two directions on (one pair per device for the whole process, like
+    the communication stream); n = 1: both directions on one stream"""
+    if n == 1:
+        return [_comm_stream(device, -1)] * 2
+    out = []
+    for k in (0, 1):
+        key = (str(device), "copy", k)
+        if key not in _COMM_STREAMS:
+            _COMM_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1)
+        out.append(_COMM_STREAMS[key])
+    return out
+
+
 def _crossing_sets(stencil):
     e = np.array(stencil.e)
     up = [int(q) for q in np.nonzero(e[:, 2] == 1)[0]]     # move to +z: fill the lower ghost
@@ -156,6 +174,137 @@ class _PeerWindow:
         h.wait_signal(s.prev, 0, self.WAIT_MS)
         self.count += 1
         return self.local[p, 1], self.local[p, 0]
+
+
+class _DevicePointer:
+    """a raw device pointer as something ``torch.as_tensor`` can wrap without copying"""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+
+
+class _CopyWindow:
+    """Receive windows for the halo transport that needs no compute unit (``transport="copy"``).
+
+    Every rank allocates one block of device memory the other processes of the node can map (``lt_ipc_alloc``):
+    2 parities x 2 directions of halo messages, one 64-bit arrival counter per direction and a time-out word.  The
+    ranks exchange the 64-byte handles through the process group and open those of their two z-neighbours.  An
+    exchange is then, on the sender's side: two device-to-device copies WITHOUT compute units (``lt_halo_copy``: an
+    SDMA engine, over xGMI) from the buffers the edge launch wrote into the neighbours' windows, each followed by
+    the write of the exchange counter into the neighbour's arrival word (``lt_flag_write``: a stream memory
+    operation); and on the receiver's: one polling wave per direction (``lt_flag_wait``; no LDS, gives up after a
+    second and says so).  RCCL's copy kernel -- 64 workgroups with 20 KB of LDS each, which cannot share a compute
+    unit with a 150 KB sweep workgroup -- is not involved.
+
+    ``slot(p, 0)`` receives what the lower neighbour sends upwards, ``slot(p, 1)`` what the upper one sends downwards;
+    p is the parity of the exchange counter.  A neighbour writes parity p again two exchanges later, after it has
+    seen my counter of the exchange in between, which I write (in stream order) after the launch that read parity p
+    has finished: no barrier is needed (the argument of ``_PeerWindow``)."""
+
+    def __init__(self, shape, dtype, device, slab: ZSlab, group, engine: int = 1, flag_how: int = 1):
+        import ctypes
+        from ._native import load_library
+        self.lib = load_library()
+        self.slab, self.device, self.dtype = slab, torch.device(device), dtype
+        self.shape = tuple(int(v) for v in shape)
+        self.engine, self.flag_how = int(engine), int(flag_how)
+        esize = torch.empty((), dtype=dtype).element_size()
+        self.msg_bytes = int(np.prod(self.shape)) * esize
+        self.msg_stride = -(-self.msg_bytes // 256) * 256
+        self.flag_offset = 4 * self.msg_stride
+        total = self.flag_offset + 256
+        base, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.lt_ipc_alloc(total, ctypes.byref(base), handle))
+        self.base = int(base.value)
+        self._opened = []
+        if slab.world_size == 1:
+            self.at_prev = self.at_next = self.base          # my own neighbour: no mapping needed
+        else:
+            # (nobody writes into a window before its owner has zeroed it: lt_ipc_alloc does so, synchronously, before
+            # the handle is published)
+            handles = [None] * slab.world_size
+            dist.all_gather_object(handles, bytes(handle.raw), group=group)
+
+            def mapped(rank):
+                out = ctypes.c_void_p()
+                with torch.cuda.device(self.device):
+                    self._check(self.lib.lt_ipc_open(handles[rank], ctypes.byref(out)))
+                self._opened.append(int(out.value))
+                return int(out.value)
+            self.at_prev = mapped(slab.prev)
+            self.at_next = self.at_prev if slab.next == slab.prev else mapped(slab.next)
+        typestr = {torch.float32: "<f4", torch.float64: "<f8"}[dtype]
+        self._local = [[torch.as_tensor(_DevicePointer(self.base + (2 * p + d) * self.msg_stride, self.shape, typestr),
+                                        device=self.device) for d in (0, 1)] for p in (0, 1)]
+        self._timed_out = torch.as_tensor(_DevicePointer(self.base + self.flag_offset + 64, (1,), "<i4"), device=self.device)
+        self.count = 0
+        self.engines_used = set()
+        one = os.environ.get("LT_SLAB_COPY_STREAMS", "2") == "1"
+        self._streams = _copy_streams(self.device, 1 if one else 2)
+
+    def _check(self, code):
+        if code != 0:
+            raise LettuceException(f"copy transport: {self.lib.lt_last_error().decode('utf-8', 'replace')}")
+
+    def send(self, send_down: torch.Tensor, send_up: torch.Tensor):
+        """behind what the current stream holds so far: my downward message into the lower neighbour's slot (p, 1), my
+        upward one into the upper neighbour's slot (p, 0), each followed by the counter of this exchange.  The two
+        directions go through a stream of their own each -- a copy engine moves 20 MB in ~0.35 ms, two engines do the
+        two messages side by side (one stream: one after the other, 0.7 ms: longer than the sweep they hide behind) --
+        and the current stream continues when both are through (the launch that overwrites the send buffers two
+        double steps later is ordered behind it)."""
+        import ctypes
+        p, cur = self.count & 1, torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        used = ctypes.c_int32(0)
+        for side, (base, d, msg) in zip(self._streams, ((self.at_prev, 1, send_down), (self.at_next, 0, send_up))):
+            side.wait_event(ready)
+            stream = ctypes.c_void_p(side.cuda_stream)
+            self._check(self.lib.lt_halo_copy(ctypes.c_void_p(base + (2 * p + d) * self.msg_stride),
+                                              ctypes.c_void_p(msg.data_ptr()), self.msg_bytes, self.engine, stream,
+                                              ctypes.byref(used)))
+            self.engines_used.add("copy engine (no compute units)" if used.value else "runtime's device-to-device copy")
+            self._check(self.lib.lt_flag_write(ctypes.c_void_p(base + self.flag_offset + 8 * d), self.count + 1,
+                                               self.flag_how, stream))
+            cur.wait_stream(side)
+
+    def wait(self):
+        """on the current stream: wait for both neighbours' messages of this exchange; returns (message from above,
+        message from below)"""
+        import ctypes
+        p, stream = self.count & 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for d in (1, 0):
+            self._check(self.lib.lt_flag_wait(ctypes.c_void_p(self.base + self.flag_offset + 8 * d), self.count + 1,
+                                              ctypes.c_void_p(self._timed_out.data_ptr()), stream))
+        self.count += 1
+        return self._local[p][1], self._local[p][0]
+
+    def timed_out(self) -> bool:
+        """did a polling wave give up since the last call?  (synchronises)"""
+        flag = bool(int(self._timed_out.item()))
+        if flag:
+            self._timed_out.zero_()
+        return flag
+
+    def close(self):
+        if getattr(self, "base", None):
+            try:
+                torch.cuda.synchronize(self.device)
+                with torch.cuda.device(self.device):
+                    for ptr in self._opened:
+                        self.lib.lt_ipc_close(ptr)
+                    self.lib.lt_ipc_free(self.base)
+            finally:
+                self.base, self._opened = 0, []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class SlabKineticEnergy:
@@ -286,10 +435,18 @@ class SlabSimulation:
                            and dist.is_initialized())
         self._host_transport = ((slab.world_size > 1 or self._force_p2p)
                                 and dist.get_backend(group) != "nccl")
-        if transport not in ("rccl", "window"):
+        if transport not in ("rccl", "window", "copy"):
             raise LettuceException(f"unknown slab transport '{transport}'")
         self.transport = transport
         self._window = None
+        self._cw = None
+        if transport == "copy":
+            if self.context.device.type != "cuda" or (slab.world_size > 1 and not (dist.is_available() and dist.is_initialized())):
+                raise LettuceException("the copy transport needs device memory (and an initialised process group "
+                                       "with more than one rank)")
+            self._cw = _CopyWindow(shape, self.f.dtype, self.f.device, slab, group,
+                                   engine=int(os.environ.get("LT_SLAB_COPY_ENGINE", "1")),
+                                   flag_how=int(os.environ.get("LT_SLAB_FLAG_HOW", "1")))
         if transport == "window":
             if self.context.device.type != "cuda" or not (dist.is_available() and dist.is_initialized()):
                 raise LettuceException("the window transport needs device memory and an initialised "
@@ -400,6 +557,18 @@ class SlabSimulation:
         e_z = +1 populations of my top plane to the upper neighbour's lower ghost plane.  One
         packed message per direction.  Returns a callable that completes the exchange (waits
         for the transfers and unpacks)."""
+        nzl, s = self.nzl, self.slab
+        if self._cw is not None:
+            if not packed:
+                self._pack(buf, 1, -1, self._send_down)
+                self._pack(buf, nzl, +1, self._send_up)
+            self._cw.send(self._send_down, self._send_up)
+
+            def finish_copy():
+                from_above, from_below = self._cw.wait()
+                self._unpack(buf, nzl + 1, -1, from_above)
+                self._unpack(buf, 0, +1, from_below)
+            return finish_copy
         nzl, s = self.nzl, self.slab
         if self._window is not None:
             if not packed:
@@ -516,8 +685,14 @@ class SlabSimulation:
                 r(self)
         if self.context.device.type == "cuda":
             torch.cuda.synchronize(self.context.device)
+        elapsed = timer() - beg
+        if self._cw is not None and self._cw.timed_out():
+            # a polling wave gave up (it waits about a second): the launch behind it read a message that had not
+            # arrived.  Raised here, after the exchanges of the call, so that the ranks stay in step
+            raise LettuceException("copy transport: timed out waiting for a neighbour's halo message; the "
+                                   "populations of this call are not valid")
         nx, ny, _ = self.slab.global_resolution
-        return num_steps * nx * ny * self.nzl / 1e6 / (timer() - beg)
+        return num_steps * nx * ny * self.nzl / 1e6 / elapsed
 
     @property
     def units(self):
@@ -670,6 +845,10 @@ class TwoStepSlabSimulation(SlabSimulation):
         """the halo messages of one double step travel (no packing, no unpacking); returns (message from below,
         message from above) once they have arrived -- in stream order"""
         s = self.slab
+        if self._cw is not None:
+            self._cw.send(send_down, send_up)
+            from_above, from_below = self._cw.wait()
+            return from_below, from_above
         if s.world_size == 1 and not self._force_p2p:
             return send_up, send_down                 # my own messages: what left upwards arrives from below
         host = self._host_transport and send_down.is_cuda
@@ -717,6 +896,17 @@ class TwoStepSlabSimulation(SlabSimulation):
         planes, and vice versa."""
         eng, s = self.engine, self.slab
         self._ghost_src = None                        # this exchange ends in the ghost planes of ``buf``
+        if self._cw is not None:
+            if not packed:
+                eng.pack_two_step(buf, -1, self._send_down)
+                eng.pack_two_step(buf, +1, self._send_up)
+            self._cw.send(self._send_down, self._send_up)
+
+            def finish_copy():
+                from_above, from_below = self._cw.wait()
+                eng.unpack_two_step(buf, +1, from_above)
+                eng.unpack_two_step(buf, -1, from_below)
+            return finish_copy
         if self._window is not None:
             if not packed:
                 to_prev, to_next = self._window.targets()

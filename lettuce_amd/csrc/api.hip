@@ -67,6 +67,26 @@ __global__ void __launch_bounds__(256) probe_copy_kernel(const probe_f4 *__restr
   }
 }
 
+// One wave: returns when *flag >= at_least (a neighbour rank's copy engine has delivered its halo message and the
+// flag write that follows it in that rank's stream has landed), or after about a second, setting *timed_out -- an exit
+// every launch reaches.  Relaxed polls at SYSTEM scope (the writer is another device or a copy engine), one acquire
+// at the end; no LDS, one wave: it shares a CU with a 150 KB sweep workgroup.
+__global__ void wait_flag_kernel(const unsigned long long *flag, unsigned long long at_least, unsigned *timed_out) {
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < at_least) {
+    __builtin_amdgcn_s_sleep(127);
+    if (wall_clock64() - t0 > 100000000ll) {           // 100 MHz: one second
+      __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+__global__ void write_flag_kernel(unsigned long long *flag, unsigned long long value) {
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // first-use check of the masked two-step kernels (run_canary): synthetic populations -- positive, near 1 / Q, a
 // different value in nearly every slot -- and a bit-for-bit comparison of two population fields over a plane range
 template <typename T>
@@ -1579,6 +1599,75 @@ int lt_plan_set_two_step(lt_plan *p, int32_t mode, int32_t planes_per_workgroup)
   if (p->seg_len != planes_per_workgroup) p->canary = 0;   // another segment length takes other paths of the sweep
   p->two_step = mode;
   p->seg_len = planes_per_workgroup;
+  return LT_OK;
+}
+
+// ---- halo transport without compute units (include/lettuce_hip.h) -------------------------------------------------
+int lt_halo_copy(void *dst, const void *src, int64_t n_bytes, int32_t engine, void *stream, int32_t *engine_used) {
+  if (!dst || !src || n_bytes <= 0) return fail(LT_ERR_INVALID, "halo copy: null buffer or %lld bytes", (long long)n_bytes);
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  if (engine_used) *engine_used = 0;
+  if (engine == 1) {
+    // device-to-device WITHOUT compute units: the runtime hands the copy to an SDMA engine (over xGMI when dst is a
+    // peer's mapped buffer) instead of launching a blit kernel
+    if (hipMemcpyAsync(dst, src, (size_t)n_bytes, hipMemcpyDeviceToDeviceNoCU, hs) == hipSuccess) {
+      if (engine_used) *engine_used = 1;
+      return LT_OK;
+    }
+    (void)hipGetLastError();                 // not offered for this pair of buffers: the ordinary copy below
+  }
+  LT_HIP(hipMemcpyAsync(dst, src, (size_t)n_bytes, hipMemcpyDeviceToDevice, hs));
+  return LT_OK;
+}
+int lt_flag_write(uint64_t *flag, uint64_t value, int32_t how, void *stream) {
+  if (!flag) return fail(LT_ERR_INVALID, "null flag");
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  if (how == 1) {
+    // a stream memory operation: the command processor writes the word when the stream gets there (no kernel)
+    if (hipStreamWriteValue64(hs, flag, value, 0) == hipSuccess) return LT_OK;
+    (void)hipGetLastError();
+  }
+  hipLaunchKernelGGL(write_flag_kernel, dim3(1), dim3(1), 0, hs, reinterpret_cast<unsigned long long *>(flag),
+                     (unsigned long long)value);
+  LT_HIP(hipGetLastError());
+  return LT_OK;
+}
+int lt_flag_wait(const uint64_t *flag, uint64_t at_least, uint32_t *timed_out, void *stream) {
+  if (!flag || !timed_out) return fail(LT_ERR_INVALID, "null flag / time-out word");
+  hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const unsigned long long *>(flag), (unsigned long long)at_least, timed_out);
+  LT_HIP(hipGetLastError());
+  return LT_OK;
+}
+// Device memory other processes of the node can map (hipIpc*): the receive windows of the copy transport
+int lt_ipc_alloc(int64_t n_bytes, void **dev_out, void *handle_out_64_bytes) {
+  if (!dev_out || !handle_out_64_bytes || n_bytes <= 0) return fail(LT_ERR_INVALID, "ipc alloc: null argument or %lld bytes", (long long)n_bytes);
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+  void *p = nullptr;
+  if (hipMalloc(&p, (size_t)n_bytes) != hipSuccess) return fail(LT_ERR_ALLOC, "hipMalloc of %lld bytes (ipc window) failed", (long long)n_bytes);
+  hipIpcMemHandle_t h;
+  const hipError_t e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess) { (void)hipFree(p); return fail(LT_ERR_HIP, "hipIpcGetMemHandle failed: %s", hipGetErrorString(e)); }
+  LT_HIP(hipMemset(p, 0, (size_t)n_bytes));
+  memcpy(handle_out_64_bytes, &h, sizeof h);
+  *dev_out = p;
+  return LT_OK;
+}
+int lt_ipc_open(const void *handle_64_bytes, void **dev_out) {
+  if (!handle_64_bytes || !dev_out) return fail(LT_ERR_INVALID, "ipc open: null argument");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle_64_bytes, sizeof h);
+  LT_HIP(hipIpcOpenMemHandle(dev_out, h, hipIpcMemLazyEnablePeerAccess));
+  return LT_OK;
+}
+int lt_ipc_close(void *mapped) {
+  if (!mapped) return LT_OK;
+  LT_HIP(hipIpcCloseMemHandle(mapped));
+  return LT_OK;
+}
+int lt_ipc_free(void *dev) {
+  if (!dev) return LT_OK;
+  LT_HIP(hipFree(dev));
   return LT_OK;
 }
 

@@ -16,7 +16,8 @@ sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, res, steps, dtype_name, overlap, out_dir, driver="SlabSimulation", signalled=False):
+def _worker(rank, world, port, res, steps, dtype_name, overlap, out_dir, driver="SlabSimulation", signalled=False,
+            transport="rccl"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -27,8 +28,12 @@ def _worker(rank, world, port, res, steps, dtype_name, overlap, out_dir, driver=
     flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 400, 0.1, lt.D3Q19(), slab=slab)
     kwargs = {"signalled": True} if signalled else {}
     sim = getattr(lt, driver)(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab,
-                              overlap=overlap, **kwargs)
+                              overlap=overlap, transport=transport, **kwargs)
     sim(steps)
+    if transport == "copy":
+        assert sim._cw is not None and sim._cw.count > 0 and not sim._cw.timed_out()
+        if driver == "TwoStepSlabSimulation":
+            assert sim._direct_ok()
     if signalled:
         assert sim._signalled_ok() and not sim.engine.wait_timed_out()
     f1 = sim.gather_f()
@@ -76,6 +81,30 @@ def test_two_step_slab_ranks_sharing_one_gpu(tmp_path, world, overlap, steps, dt
     np.testing.assert_allclose(got["f1"], ref.f.numpy(), rtol=0, atol=tol * float(np.abs(ref.f.numpy()).max()))
 
 
+@pytest.mark.parametrize("driver,world,steps,dtype_name",
+                         [("TwoStepSlabSimulation", 2, 9, "float32"), ("TwoStepSlabSimulation", 3, 6, "float64"),
+                          ("TwoStepSlabSimulation", 4, 8, "float32"), ("SlabSimulation", 2, 5, "float64"),
+                          ("SlabSimulation", 3, 4, "float32")],
+                         ids=["two-step-2ranks", "two-step-3ranks-fp64", "two-step-4ranks", "single-step-2ranks-fp64",
+                              "single-step-3ranks"])
+def test_copy_transport_between_processes_sharing_one_gpu(tmp_path, driver, world, steps, dtype_name):
+    """transport="copy" as the ranks of a node use it: every process allocates its receive window with lt_ipc_alloc,
+    the 64-byte handles travel through the process group, every rank maps its neighbours' windows (hipIpcOpenMemHandle)
+    and the halo messages move by device-to-device copies without compute units, each followed by a counter the
+    receiver's polling wave waits for -- real kernels, real inter-process mapping, 2-4 ranks on the one GPU of the
+    box, odd and even step counts, against the single-domain oracle."""
+    from oracle import lettuce_oracle as orc
+    res = [64, 16, 12 * world]
+    port = 29300 + (os.getpid() % 500) + 10 * world + (5 if driver == "SlabSimulation" else 0)
+    mp.spawn(_worker, args=(world, port, res, steps, dtype_name, True, str(tmp_path), driver, False, "copy"),
+             nprocs=world, join=True)
+    got = np.load(tmp_path / "out.npz")
+    ref = orc.taylor_green(res, 400, 0.1, "D3Q19", getattr(torch, dtype_name))
+    ref.step(steps)
+    tol = 1e-5 if dtype_name == "float32" else 1e-13
+    np.testing.assert_allclose(got["f1"], ref.f.numpy(), rtol=0, atol=tol * float(np.abs(ref.f.numpy()).max()))
+
+
 def _two_step_identity_worker(rank, port, res, steps, transport, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -106,7 +135,7 @@ def _two_step_identity_worker(rank, port, res, steps, transport, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("transport", ["rccl", "window", "rccl-signalled"])
+@pytest.mark.parametrize("transport", ["rccl", "window", "rccl-signalled", "copy"])
 def test_two_step_slab_is_bit_identical_to_the_single_step_slab(tmp_path, transport):
     """Same kernels' arithmetic, different schedule and halo: the two drivers must agree bit for bit
     (single rank exchanging with itself through RCCL / through its own peer window).  "rccl-signalled": one
