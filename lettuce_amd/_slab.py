@@ -111,7 +111,7 @@ def _copy_streams(device, n):
     """the streams the copy transport issues its two directions on (one pair per device for the whole process, like
     the communication stream); n = 1: both directions on one stream"""
     if n == 1:
-        return [_comm_stream(device, -1)] * 2
+        return [None, None]                      # the stream that is current when send() is called
     out = []
     for k in (0, 1):
         key = (str(device), "copy", k)
@@ -200,9 +200,17 @@ class _CopyWindow:
     ``slot(p, 0)`` receives what the lower neighbour sends upwards, ``slot(p, 1)`` what the upper one sends downwards;
     p is the parity of the exchange counter.  A neighbour writes parity p again two exchanges later, after it has
     seen my counter of the exchange in between, which I write (in stream order) after the launch that read parity p
-    has finished: no barrier is needed (the argument of ``_PeerWindow``)."""
+    has finished: no barrier is needed (the argument of ``_PeerWindow``).
 
-    def __init__(self, shape, dtype, device, slab: ZSlab, group, engine: int = 1, flag_how: int = 1):
+    ``engine``: 0 = the runtime's device-to-device copy (default): to a PEER's window that is an SDMA engine over xGMI;
+    when source and destination are the same device -- the one-GPU rehearsal -- a blit kernel without LDS that shares
+    the compute units with the sweep (20 MB in ~20 us); 1 = ask for a copy without compute units everywhere
+    (hipMemcpyDeviceToDeviceNoCU).  Measured in the rehearsal (one MI355X, 512 x 512 x 64, ms per step, same box;
+    profiles/r04c_slab_copy_transport.json): RCCL to self 0.3212, engine 0 0.3064, engine 1 0.322-0.327 with a
+    scatter of 4 % between batches -- an SDMA engine moves a 20 MB message within one device at ~57 GB/s (0.35 ms),
+    two of them beside a sweep that saturates HBM disturb it more than RCCL's kernel does."""
+
+    def __init__(self, shape, dtype, device, slab: ZSlab, group, engine: int = 0, flag_how: int = 1):
         import ctypes
         from ._native import load_library
         self.lib = load_library()
@@ -215,8 +223,14 @@ class _CopyWindow:
         self.flag_offset = 4 * self.msg_stride
         total = self.flag_offset + 256
         base, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
-        with torch.cuda.device(self.device):
-            self._check(self.lib.lt_ipc_alloc(total, ctypes.byref(base), handle))
+        self._torch_backing = None
+        if slab.world_size == 1 and os.environ.get("LT_SLAB_WINDOW_TORCH") == "1":
+            # experiment: the window of a rank that is its own neighbour needs no export; take it from torch's allocator
+            self._torch_backing = torch.zeros(total, dtype=torch.uint8, device=self.device)
+            base = ctypes.c_void_p(self._torch_backing.data_ptr())
+        else:
+            with torch.cuda.device(self.device):
+                self._check(self.lib.lt_ipc_alloc(total, ctypes.byref(base), handle))
         self.base = int(base.value)
         self._opened = []
         if slab.world_size == 1:
@@ -241,8 +255,14 @@ class _CopyWindow:
         self._timed_out = torch.as_tensor(_DevicePointer(self.base + self.flag_offset + 64, (1,), "<i4"), device=self.device)
         self.count = 0
         self.engines_used = set()
-        one = os.environ.get("LT_SLAB_COPY_STREAMS", "2") == "1"
-        self._streams = _copy_streams(self.device, 1 if one else 2)
+        # Both directions on the communication stream by default.  A stream of their own each lets two copy engines
+        # work side by side (an SDMA engine moves 20 MB in ~0.35 ms), but every further active hardware queue costs
+        # the sweep: in the one-GPU rehearsal two extra high-priority streams made the copy candidate 0.37 instead
+        # of 0.30 ms per step whenever RCCL's streams existed in the process too (tools/slab_order_probe.py,
+        # profiles/r04g_slab_stream_count.jsonl; GPU_MAX_HW_QUEUES = 8 / 16 changed nothing, 2 gave 0.295).
+        # LT_SLAB_COPY_STREAMS=2 to A/B on real links.
+        two = os.environ.get("LT_SLAB_COPY_STREAMS", "1") == "2"
+        self._streams = _copy_streams(self.device, 2 if two else 1)
 
     def _check(self, code):
         if code != 0:
@@ -250,18 +270,20 @@ class _CopyWindow:
 
     def send(self, send_down: torch.Tensor, send_up: torch.Tensor):
         """behind what the current stream holds so far: my downward message into the lower neighbour's slot (p, 1), my
-        upward one into the upper neighbour's slot (p, 0), each followed by the counter of this exchange.  The two
-        directions go through a stream of their own each -- a copy engine moves 20 MB in ~0.35 ms, two engines do the
-        two messages side by side (one stream: one after the other, 0.7 ms: longer than the sweep they hide behind) --
-        and the current stream continues when both are through (the launch that overwrites the send buffers two
-        double steps later is ordered behind it)."""
+        upward one into the upper neighbour's slot (p, 0), each followed by the counter of this exchange -- on the
+        current stream, or (LT_SLAB_COPY_STREAMS=2) on a stream of its own per direction, after which the current
+        stream continues when both are through (the launch that overwrites the send buffers two double steps later
+        is ordered behind it)."""
         import ctypes
         p, cur = self.count & 1, torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(cur)
         used = ctypes.c_int32(0)
         for side, (base, d, msg) in zip(self._streams, ((self.at_prev, 1, send_down), (self.at_next, 0, send_up))):
-            side.wait_event(ready)
+            if side is None:
+                side = cur
+            else:
+                side.wait_event(ready)
             stream = ctypes.c_void_p(side.cuda_stream)
             self._check(self.lib.lt_halo_copy(ctypes.c_void_p(base + (2 * p + d) * self.msg_stride),
                                               ctypes.c_void_p(msg.data_ptr()), self.msg_bytes, self.engine, stream,
@@ -269,7 +291,8 @@ class _CopyWindow:
             self.engines_used.add("copy engine (no compute units)" if used.value else "runtime's device-to-device copy")
             self._check(self.lib.lt_flag_write(ctypes.c_void_p(base + self.flag_offset + 8 * d), self.count + 1,
                                                self.flag_how, stream))
-            cur.wait_stream(side)
+            if side is not cur:
+                cur.wait_stream(side)
 
     def wait(self):
         """on the current stream: wait for both neighbours' messages of this exchange; returns (message from above,
@@ -296,7 +319,8 @@ class _CopyWindow:
                 with torch.cuda.device(self.device):
                     for ptr in self._opened:
                         self.lib.lt_ipc_close(ptr)
-                    self.lib.lt_ipc_free(self.base)
+                    if self._torch_backing is None:
+                        self.lib.lt_ipc_free(self.base)
             finally:
                 self.base, self._opened = 0, []
 
@@ -445,7 +469,7 @@ class SlabSimulation:
                 raise LettuceException("the copy transport needs device memory (and an initialised process group "
                                        "with more than one rank)")
             self._cw = _CopyWindow(shape, self.f.dtype, self.f.device, slab, group,
-                                   engine=int(os.environ.get("LT_SLAB_COPY_ENGINE", "1")),
+                                   engine=int(os.environ.get("LT_SLAB_COPY_ENGINE", "0")),
                                    flag_how=int(os.environ.get("LT_SLAB_FLAG_HOW", "1")))
         if transport == "window":
             if self.context.device.type != "cuda" or not (dist.is_available() and dist.is_initialized()):
