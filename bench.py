@@ -641,6 +641,23 @@ class Ranks:
         self.dist.all_gather(out, mine)
         return [round(float(x.item()), 6) for x in out]
 
+    def devices(self):
+        """what every rank computes on, all-gathered: the device's UUID (RCCL ranks) or host + pid (the CPU test) -- the
+        record that the job really ran on `world` DISTINCT devices"""
+        import hashlib
+        import socket
+        if self.cuda:
+            ident = str(getattr(torch.cuda.get_device_properties(self.device), "uuid", "")) or f"cuda:{self.device.index}"
+            ident = f"{socket.gethostname()}/{ident}"
+        else:
+            ident = f"{socket.gethostname()}/cpu-process-{os.getpid()}"
+        mine = torch.tensor(list(hashlib.sha256(ident.encode()).digest()[:8]), dtype=torch.uint8, device=self.device)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        ids = [bytes(t.cpu().tolist()).hex() for t in out]
+        return {"ranks": self.world, "distinct_devices": len(set(ids)), "device_ids_sha256_8": ids,
+                "rank0_device": ident}
+
     def release(self):
         if self.cuda:
             torch.cuda.empty_cache()
@@ -699,20 +716,28 @@ def slab_bench(args, lt, dist, world, rank, local_rank, device):
 
     what = (f"{flow_name} {stencil_name} BGK {'fp32' if dtype == torch.float32 else 'fp64'} "
             f"{global_res[0]}x{global_res[1]}x{global_res[2]} ({nodes_per_rank} nodes per GPU)")
+    # the CPU baseline of the N = 1 line, measured on rank 0's host cores before the candidates while the other ranks
+    # wait in the first collective of the loop (same per-GPU node count; ~20 s)
+    cpu_row = None
+    if rank == 0 and not args.no_cpu_baseline and args.workload == "cfg3":
+        cpu_row = cpu_baseline(256 if n == 256 else n, args.cpu_baseline_steps)
+        cpu_row["sample"] += "; measured on rank 0 before the process group's first collective"
+    traffic_key = {"cfg3": "slab_tgv3d_d3q19_bgk_f32_512x512x64", "cfg5": "slab_shear3d_d3q19_bgk_f64_384x384x96"}.get(args.workload)
     candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank, bytes_per_node,
-                   "f32" if dtype == torch.float32 else "f64")
+                   "f32" if dtype == torch.float32 else "f64", cpu_baseline_row=cpu_row,
+                   traffic_workload=traffic_key if n == 256 else None)
     dist.barrier(device_ids=[local_rank])
     dist.destroy_process_group()
 
 
 def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank, bytes_per_node, dtype_tag,
-                   probe_steps=None):
+                   probe_steps=None, cpu_baseline_row=None, traffic_workload=None):
     """Try the candidates in order, time each one that passes its checks, hold the best line; rank 0 prints the held
     line at the end -- or the watchdog does -- whatever the later candidates did.  ``build(driver, transport)``
     returns a slab driver (callable with a step count, ``local_f()``, ``engine.kernel_name()``)."""
     world, rank, device = ranks.world, ranks.rank, ranks.device
     barrier, all_ranks, max_over_ranks = ranks.barrier, ranks.all_ranks, ranks.max_over_ranks
-    probe, checks, failures = {}, {}, {}
+    probe, checks, failures, seen_box = {}, {}, {}, {}
 
     def nothing_held(why):
         return {"metric": "MLUPS (million lattice updates/s) D3Q19 256³ TGV; achieved HBM GB/s vs peak",
@@ -721,10 +746,12 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
                 "dtype": dtype_tag, "data": "synthetic",
                 "config": {"workload": what, "global_resolution": global_res, "parallelism": f"z-slab x{world}",
                            "transport": {"chosen": None, "warmup_ms_per_step": probe, "checks": checks,
-                                         "failures": failures, "ranks_seen": world, "aborted": why}},
-                "roofline": None, "cpu_baseline": None, "verified": None}
+                                         "failures": failures, "ranks_seen": seen_box.get("seen", world),
+                                         "aborted": why}},
+                "roofline": None, "cpu_baseline": cpu_baseline_row, "verified": None}
 
     held = HeldLine(rank, nothing_held)
+    seen = seen_box["seen"] = ranks.devices()             # collective: before any candidate
     reference = {}                     # the first candidate's populations after the probe and after its timed batches
     probe_steps = max(args.warmup, 60) if probe_steps is None else probe_steps
     window_ok = None
@@ -753,8 +780,12 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
         # two-step driver does two updates per launch, so HBM physically carries half of that
         eff = bytes_per_node * nodes_per_rank * args.steps / elapsed / 1e9
         per_launch = 2 if driver == "two-step" else 1
+        # HBM bytes per launch of the dominant kernel (the sweep between the cuts / the interior launch) from the
+        # committed PMC passes of the one-rank rehearsal of this workload (profiles/traffic.json; null when the file
+        # belongs to other kernel sources)
+        traffic = traffic_from_profile(kernel, traffic_workload) if traffic_workload else None
         roofline = {"bound": "hbm", "achieved": round(eff, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(eff / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
+                    "frac": round(eff / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
                     "lattice_updates_per_node_per_launch": per_launch, "physical_GBps": round(eff / per_launch, 1),
                     "physical_frac": round(eff / per_launch / HBM_PEAK_GBS, 4),
                     "note": f"whole-step rate per GPU (includes the halo exchange): {bytes_per_node} B per node and lattice "
@@ -771,7 +802,7 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
                                            "that presents the populations in lettuce's post-streaming convention runs "
                                            "when they are read (not inside the timed batches)",
                        "transport": {"chosen": name, "warmup_ms_per_step": probe, "checks": checks,
-                                     "failures": failures, "ranks_seen": world}},
+                                     "failures": failures, "ranks_seen": seen}},
             "batches_ms_per_step": [round(t / args.steps * 1e3, 5) for t in batch_s],
             "timing": (f"median of {len(batch_s)} timed batches (barrier + device synchronise on both sides, max over "
                        f"ranks); a batch is the {args.steps}-step call repeated {repeat}x back to back "
@@ -779,7 +810,7 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
             "repeats_per_batch": repeat,
             "roofline": roofline,
             "verified": verified,
-            "cpu_baseline": None,
+            "cpu_baseline": cpu_baseline_row,
         }
 
     for index, (driver, transport) in enumerate(wanted):

@@ -79,8 +79,9 @@ def main():
     else:
         wanted = [("single-step", "rccl")] + [("two-step", t) for t in stubs]
     ranks = bench.Ranks(dist, world, rank, 0, torch.device("cpu"))
+    cpu_row = {"value": 1.0, "unit": "MLUPS", "cores": 1, "kind": "port", "sample": "stub"} if rank == 0 else None
     bench.candidate_loop(args, ranks, wanted, build, "stub workload", res, res[0] * res[1] * slab.nz_local, 304, "f64",
-                         probe_steps=2)
+                         probe_steps=2, cpu_baseline_row=cpu_row, traffic_workload="no such workload")
     dist.barrier()
     dist.destroy_process_group()
 

@@ -27,6 +27,12 @@ def _check_line(lines):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0 and line["unit"] == "MLUPS"
     assert len(line["batches_ms_per_step"]) == 2
+    # the N > 1 line is self-sufficient -- the CPU baseline rank 0 measured, the roofline object
+    # with its traffic field (null here: no PMC pass of a stub workload), and the devices RCCL's ranks sat on
+    assert line["cpu_baseline"] == {"value": 1.0, "unit": "MLUPS", "cores": 1, "kind": "port", "sample": "stub"}
+    assert "traffic" in line["roofline"] and line["roofline"]["traffic"] is None
+    seen = line["config"]["transport"]["ranks_seen"]
+    assert seen["ranks"] == 2 and seen["distinct_devices"] == 2 and len(seen["device_ids_sha256_8"]) == 2
     return line, line["config"]["transport"]
 
 
@@ -76,6 +82,7 @@ def test_a_reference_candidate_that_never_returns_ends_in_a_line_that_says_so():
     assert r.returncode != 0
     assert len(lines) == 1, (lines, r.stderr[-2000:])
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["value"] == 0.0
+    assert line["n_gpus"] == 2 and line["value"] == 0.0 and line["cpu_baseline"]["kind"] == "port"
     t = line["config"]["transport"]
+    assert t["ranks_seen"]["distinct_devices"] == 2
     assert t["chosen"] is None and "watchdog" in t["aborted"] and "single-step/never-returns" in t["aborted"]

@@ -1,4 +1,4 @@
-"""Summarise the rocprofv3 runs of tools/gpu_round3.sh into profiles/:
+"""Summarise the rocprofv3 runs of tools/gpu_round.sh (rounds 3+) into profiles/:
   <tag>_kernel_stats.csv           rocprofv3 --kernel-trace --stats of the judged command (python bench.py): LBM kernels +
                                    the top other rows
   <tag>_other_kernel_stats.csv     the same for the other BASELINE workloads (tools/profile_workload.py), LBM kernels only
@@ -18,7 +18,7 @@ are those of the two lattice updates per node they perform per launch.
 import csv, glob, json, os, statistics, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WORKLOADS = ["cfg2", "cfg4", "cfg4bgk", "obst19", "cfg5"]
+WORKLOADS = ["cfg2", "cfg4", "cfg4bgk", "obst19", "cfg5", "slab", "slab5"]
 
 
 def is_lbm(name):

@@ -31,6 +31,20 @@ elif which == "cfg5":
     flow = lt.DoublyPeriodicShear3D(ctx, [384, 384, 96], 10000, 0.1)
     sim = lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])
     q, esize, key = 19, 8, "shear3d_d3q19_bgk_f64_384x384x96"
+elif which in ("slab", "slab5"):
+    # one rank of the multi-GPU path by itself (no transport: the halo messages stay where the edge launch wrote them):
+    # the per-GPU slab of cfg3 / cfg5 through the two-step slab driver -- edge launch + sweep per double step
+    res, dt, q, esize = (([512, 512, 64], torch.float32, 19, 4) if which == "slab" else ([384, 384, 96], torch.float64, 19, 8))
+    ctx = lt.Context(dev, dt, True)
+    slab = lt.ZSlab(res, 0, 1)
+    if which == "slab":
+        flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 1600, 0.1, lt.D3Q19(), slab=slab)
+        key = "slab_tgv3d_d3q19_bgk_f32_512x512x64"
+    else:
+        flow = lt.DoublyPeriodicShear3D(ctx, slab.extended_resolution, 10000, 0.1, slab=slab)
+        key = "slab_shear3d_d3q19_bgk_f64_384x384x96"
+    sim = lt.TwoStepSlabSimulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab)
+    flow.resolution = res                       # nodes of the slab (the extended slab was only needed for the set-up)
 else:
     raise SystemExit(f"unknown workload {which}")
 sim(3)
@@ -39,11 +53,12 @@ t0 = time.perf_counter()
 sim(steps)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-_ = flow.f
+_ = sim.f if which.startswith("slab") else flow.f
 torch.cuda.synchronize()
 n = 1
 for r in flow.resolution:
     n *= r
 print(json.dumps({"workload": key, "which": which, "nodes": n, "q": q, "esize": esize, "steps": steps,
-                  "kernel": sim._native.plan.kernel_name(), "mlups_wall": round(steps * n / dt / 1e6, 1),
-                  "last_run": sim._native.plan.last_run_info()}), flush=True)
+                  "kernel": (sim.engine if which.startswith("slab") else sim._native.plan).kernel_name(),
+                  "mlups_wall": round(steps * n / dt / 1e6, 1),
+                  "last_run": None if which.startswith("slab") else sim._native.plan.last_run_info()}), flush=True)
