@@ -102,6 +102,9 @@ typedef struct lt_plan_desc {
 typedef struct lt_plan lt_plan;
 
 int lt_abi_version(void);
+/* bit 0: the library was built with the experiment kernels (make EXPERIMENTS=1; the entry points under
+ * LT_EXPERIMENTS below) */
+int lt_build_flags(void);
 const char *lt_last_error(void);
 
 int lt_plan_create(const lt_plan_desc *desc, lt_plan **out_plan);
@@ -318,7 +321,8 @@ const char *lt_plan_kernel_name(lt_plan *plan);
  * (D3Q19 / D3Q15 fp32, BGK, reference layout): 0 = product variant, 1 = two nodes per thread in both
  * phases, 2 = two output nodes per thread, 3 = no XCD-aware renumbering of the workgroups, 4 = the round-1
  * renumbering (an eighth of the grid per XCD instead of an eighth of every segment layer), 5 = 32 x 8 tiles for
- * the slab edge launch (two workgroups per CU; measured slower: 99 against 77 us). */
+ * the slab edge launch (two workgroups per CU; measured slower: 99 against 77 us).  1, 2 and 5 are tile variants
+ * that lost their A/B: they exist in the experiments build only (LT_ERR_UNSUPPORTED otherwise). */
 int lt_plan_set_shift_policy(lt_plan *plan, int32_t policy);
 /* Diagnostic: dst[0:n_bytes] = src[0:n_bytes] with 16-byte accesses and the cache-policy bits of
  * lt_plan_set_tuning; max_blocks > 0 caps its grid (grid-stride loop).  bench.py uses it to
@@ -336,12 +340,15 @@ int lt_plan_set_graph_mode(lt_plan *plan, int32_t mode);
  * wide != 0 switches the hot kernel (fused, BGK, no masks) to its 16-byte-per-lane A/B variant,
  * whose shift handling lt_plan_set_shift_policy selects. */
 int lt_plan_set_tuning(lt_plan *plan, int32_t cache_policy, int32_t wide);
-/* THREE fused stream-collide steps in one launch (lbm3_kernel): out = (C S)^3 f with both intermediate states in
+#ifdef LT_EXPERIMENTS
+/* (experiments build only: 20 % slower per update than two updates per launch)
+ * THREE fused stream-collide steps in one launch (lbm3_kernel): out = (C S)^3 f with both intermediate states in
  * LDS -- one HBM read and one write of the populations per three lattice updates.  Periodic 3-D plans without
  * boundaries in the reference layout whose grid tiles (contiguous extent % 64 (fp32) / 32 (fp64), middle extent % 4);
  * LT_ERR_UNSUPPORTED otherwise.  Bit-identical to three lt_stream_collide calls.  Same contract as the reference's
  * native step applied three times (lettuce/cuda_native/_template.py:58-86). */
 int lt_stream_collide_thrice(lt_plan *plan, const void *f_dev, void *out_dev, double tau, void *stream);
+#endif
 
 /* Two fused steps in one launch: out = (C S)^2 f for the whole periodic grid, the intermediate
  * state staged through LDS (one HBM read and one write of the populations per two lattice updates).
@@ -416,6 +423,16 @@ int lt_plan_last_run_info(lt_plan *plan, int64_t *single_step_launches, int64_t 
  * them): -1 = automatic (3, or 4 for fp32 KBC, once the populations stream from HBM and the launch
  * fills the chip several times over; no cap otherwise), 0 = no cap, 2..8 = that many. */
 int lt_plan_set_residency(lt_plan *plan, int32_t workgroups_per_cu);
+/* Arithmetic of the BGK collision.  0 (default) = the reference's, operation for operation: every rounding of
+ * lettuce's whole-field torch operators is reproduced (ATen's summation order, u = j / rho by IEEE division, the
+ * division by the rounded constants 2 cs^2 and cs^2, no fused multiply-adds; lettuce/_flow.py:136-172,
+ * ext/_equilibrium/quadratic_equilibrium.py:11-25, ext/_collision/bgk_collision.py:17-22), so periodic BGK flows are
+ * bit-identical to the reference's CPU path.  1 = fast: the same collision to rounding level in about half the
+ * instructions (moments over opposite pairs, one reciprocal of rho, cs^2 = 1/3, contracted multiply-adds), inside
+ * the tolerances SURVEY.md 8(d) states (fp32: max |df| <= 1e-5 max |f| after 10 steps, kinetic energy 1e-6 / 5e-5
+ * over 10 / 100 steps) but NOT bit-identical to the reference; exists for BGK on periodic 3-D plans without
+ * boundaries in the reference layout, never chosen by the engine itself. */
+int lt_plan_set_arithmetic(lt_plan *plan, int32_t mode);
 /* First-use check of the two-step kernels of a plan WITH masks.  Before such a plan uses a two-step kernel for the
  * first time (lt_run's pairs, lt_resident_advance, every lt_stream_collide_twice* entry point,
  * lt_plan_two_step_admitted), one double step over all its planes is held against two one-step launches: synthetic

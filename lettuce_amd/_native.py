@@ -59,6 +59,7 @@ class _PlanDesc(ctypes.Structure):
 _vp, _i32, _i64, _dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 SYMBOLS = {
     "lt_abi_version": (ctypes.c_int, []),
+    "lt_build_flags": (ctypes.c_int, []),
     "lt_last_error": (ctypes.c_char_p, []),
     "lt_plan_create": (ctypes.c_int, [ctypes.POINTER(_PlanDesc), ctypes.POINTER(_vp)]),
     "lt_plan_destroy": (ctypes.c_int, [_vp]),
@@ -92,7 +93,6 @@ SYMBOLS = {
     "lt_plan_set_graph_mode": (ctypes.c_int, [_vp, _i32]),
     "lt_plan_set_tuning": (ctypes.c_int, [_vp, _i32, _i32]),
     "lt_plan_set_residency": (ctypes.c_int, [_vp, _i32]),
-    "lt_stream_collide_thrice": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _vp]),
     "lt_stream_collide_twice": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _vp]),
     "lt_plan_set_two_step": (ctypes.c_int, [_vp, _i32, _i32]),
     "lt_stream_collide_twice_planes": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _i64, _vp]),
@@ -130,8 +130,14 @@ SYMBOLS = {
     "lt_halo_copy": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, ctypes.POINTER(_i32)]),
     "lt_flag_write": (ctypes.c_int, [_vp, ctypes.c_uint64, _i32, _vp]),
     "lt_flag_wait": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp, _vp]),
+    "lt_plan_set_arithmetic": (ctypes.c_int, [_vp, _i32]),
     "lt_plan_set_canary": (ctypes.c_int, [_vp, _i32]),
     "lt_plan_canary_status": (ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_char_p)]),
+}
+
+# entry points of the experiments build (make -C lettuce_amd/csrc EXPERIMENTS=1): bound when the library has them
+EXPERIMENT_SYMBOLS = {
+    "lt_stream_collide_thrice": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _vp]),
 }
 
 _LIB = None
@@ -167,11 +173,20 @@ def load_library() -> ctypes.CDLL:
             raise NativeEngineError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
+    if lib.lt_build_flags() & 1:
+        for name, (restype, argtypes) in EXPERIMENT_SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = restype, argtypes
     if lib.lt_abi_version() != LT_ABI_VERSION:
         raise NativeEngineError(f"ABI mismatch: library {lib.lt_abi_version()}, "
                                 f"binding {LT_ABI_VERSION}")
     _LIB = lib
     return lib
+
+
+def experiments_built() -> bool:
+    """was the library built with the kernels that lost their A/B (make EXPERIMENTS=1)?"""
+    return bool(load_library().lt_build_flags() & 1)
 
 
 def _stream_handle() -> int:
@@ -657,6 +672,9 @@ class Plan:
     def stream_collide_thrice(self, f, out, tau):
         """out = (collide o stream)^3 f in one launch (both intermediate states in LDS; lbm3_kernel)"""
         self._tensor_ok(f, self.f_shape); self._tensor_ok(out, self.f_shape)
+        if not experiments_built():
+            raise NativeEngineError("three steps per launch: a kernel of the experiments build "
+                                    "(make -C lettuce_amd/csrc EXPERIMENTS=1)")
         self._check(self.lib.lt_stream_collide_thrice(self._handle, _ptr(f), _ptr(out), float(tau),
                                                       _stream_handle()))
         return out
@@ -744,6 +762,12 @@ class Plan:
     def unpack_two_step(self, f, side, buf):
         self._populations_ok(f); self._message_ok(buf, self.two_step_message_blocks())
         self._check(self.lib.lt_slab_unpack_two_step(self._handle, _ptr(f), int(side), _ptr(buf), _stream_handle()))
+
+    def set_arithmetic(self, mode):
+        """"exact" / 0: the reference's arithmetic operation for operation (bit-identical periodic BGK flows);
+        "fast" / 1: the same collision to rounding level in half the instructions (BGK, periodic 3-D plans)"""
+        mode = {"exact": 0, "fast": 1}.get(mode, mode)
+        self._check(self.lib.lt_plan_set_arithmetic(self._handle, int(mode)))
 
     def set_canary(self, mode: int = 1):
         """first-use check of the masked two-step kernels: 1 = on (default), 0 = trust the kernel, 2 = report a

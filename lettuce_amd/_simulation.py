@@ -116,6 +116,8 @@ class _NativeStepper:
         self._entries = [b.plan_entry(flow) for b in self.boundaries]
         self.plan = Plan(lattice, ctx.dtype, self.collision.kind, flow.resolution, self._entries,
                          device=ctx.device)
+        if getattr(self.collision, "arithmetic", "exact") != "exact":
+            self.plan.set_arithmetic(self.collision.arithmetic)      # raises where the engine has no such kernel
         self._mask_state = None
         self._carry = None      # state that allows lt_continue
         self._lazy = None       # (f*, scratch, versions) while flow.f is one streaming pass short

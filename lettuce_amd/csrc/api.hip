@@ -148,6 +148,7 @@ struct lt_plan {
   unsigned *signal_timed_out = nullptr;
   unsigned long long *signal_now = nullptr;   // where step() finds the counter for the launch being issued (or null)
   const void *ghost_lo_now = nullptr, *ghost_hi_now = nullptr;   // received halo messages the edge launch being issued reads
+  int arith = 0;             // 0 = the reference's arithmetic, operation for operation; 1 = fast (lt_plan_set_arithmetic)
   int defer_stream = 0;      // lt_run / lt_continue stop before their last (streaming) pass (lt_plan_set_deferred_stream)
   // distance between consecutive populations of the caller's buffers, in elements (lt_plan_set_population_stride);
   // 0 = dense (N).  stride_in_now / stride_out_now: what step() uses for the launch being issued when the two
@@ -182,6 +183,11 @@ namespace {
 
 // elements between consecutive populations of the caller's buffers
 long long pop_stride_of(const lt_plan *p) { return p->pop_stride > 0 ? p->pop_stride : p->N; }
+
+// the collision the kernels are asked for: the plan's, or 3 = BGK in fast arithmetic (lt_plan_set_arithmetic)
+int coll_of(const lt_plan *p) {
+  return (p->arith == 1 && p->desc.collision == LT_COLLISION_BGK) ? 3 : p->desc.collision;
+}
 
 int mem_axis_of(const lt_plan *p, int logical_axis) {
   if (p->unit.d == 1) return 0;
@@ -379,7 +385,7 @@ TwoStepTile two_step_tile_of(int d, int q, int esize, int n0, bool masked = fals
     // the 160 KB, 4 rows are used (D3Q19 fp64: 168.6 KB -> 32 x 4 tiles, 101 KB); unit.inc applies the same rule
     const int in_plane = q == 15 ? 5 : 9, crossing = (q - in_plane) / 2;
     const long long lds8 = (long long)esize * ((width + 2) * 10 * (4 * crossing + 3 * in_plane + 3 * crossing) + 2 * q);
-    if (lds8 > 160 * 1024) rows = 4;
+    if (lds8 > 160 * 1024) rows = LT_EXPERIMENTS ? 4 : 0;   // (product build: no masked two-step kernel there; it lost its A/B)
   }
   return {width, rows};
 }
@@ -556,7 +562,7 @@ int step(lt_plan *p, int mode, const void *in, void *out, double tau, long long 
   a.wrap2 = p->desc.ghost_planes ? 0 : 1;
   a.tau = tau > 0.0 ? tau : 1.0;
   a.node = p->node; a.nsm_bits = p->nsm_bits; a.bt = p->bt; a.nb = p->desc.n_boundaries;
-  a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = mode;
+  a.layout = p->desc.layout; a.coll = coll_of(p); a.mode = mode;
   a.masked = p->masked;
   a.abb_depth = p->abb_depth;
   a.abb_axis = p->masked ? masked_two_step_axis(p) : 2;
@@ -685,7 +691,7 @@ bool two_step_possible(lt_plan *p, const char **why) {
   }
   lt::StepArgs a;
   memset(&a, 0, sizeof a);
-  a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = lt::kFusedTwice;
+  a.layout = p->desc.layout; a.coll = coll_of(p); a.mode = lt::kFusedTwice;
   a.masked = p->masked;
   a.abb_axis = p->masked ? masked_two_step_axis(p) : 2;
   a.strip = p->unit.d == 2 ? tile.width : 0;
@@ -840,13 +846,14 @@ int many_max(const lt_plan *p) { return p->unit.d == 3 ? 2 : kManyMax - ((p->mas
 // grid is launch-bound; "automatic" stops at 256 x 256 nodes, 256 x 128 with masks (measured,
 // tools/small_grid_bench.py, tools/small_masked_bench.py).
 bool many_step_wanted(lt_plan *p) {
-  if (p->many == 0 || p->desc.ghost_planes || p->unit.d < 2) return false;
+  if (p->many == 0 || p->desc.ghost_planes || p->unit.d < 2 || p->arith != 0) return false;
+  if (p->unit.d == 3 && !LT_EXPERIMENTS) return false;       // lbm_many3d_kernel: slower than two launches on every grid
   if (p->masked && (p->n_abb > 1 || p->unit.d == 3)) return false;
   if (p->n0 % 8 != 0 || p->n1 % 8 != 0 || (p->unit.d == 3 && p->n2 % 8 != 0)) return false;
   if (p->unit.d == 3 && p->desc.layout != LT_LAYOUT_REFERENCE) return false;
   lt::StepArgs a;
   memset(&a, 0, sizeof a);
-  a.layout = p->desc.layout; a.coll = p->desc.collision; a.mode = lt::kFusedMany;
+  a.layout = p->desc.layout; a.coll = coll_of(p); a.mode = lt::kFusedMany;
   a.masked = p->masked;
   if (!p->unit.name(a)) return false;
   if (p->many == 1) return true;
@@ -980,6 +987,7 @@ int aux(lt_plan *p, int what, const void *f, void *rho, void *u, double *out, vo
 extern "C" {
 
 int lt_abi_version(void) { return LT_ABI_VERSION; }
+int lt_build_flags(void) { return LT_EXPERIMENTS ? 1 : 0; }
 const char *lt_last_error(void) { return g_error; }
 
 int lt_plan_create(const lt_plan_desc *d, lt_plan **out) {
@@ -1250,7 +1258,7 @@ const char *lt_plan_kernel_name(lt_plan *p) {
   if (!p) return "";
   lt::StepArgs a;
   memset(&a, 0, sizeof a);
-  a.layout = p->desc.layout; a.coll = p->desc.collision;
+  a.layout = p->desc.layout; a.coll = coll_of(p);
   // what the fused section launches: lt_run's pairs, or a two-step slab driver on a plan with two
   // ghost planes
   a.mode = (two_step_wanted(p) || p->desc.ghost_planes == 2) ? lt::kFusedTwice : lt::kFused;
@@ -1306,6 +1314,8 @@ int lt_probe_copy(void *dst, const void *src, int64_t n_bytes, int32_t cache_pol
 int lt_plan_set_shift_policy(lt_plan *p, int32_t policy) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (policy < 0 || policy > 5) return fail(LT_ERR_INVALID, "shift policy %d", policy);
+  if (!LT_EXPERIMENTS && (policy == 1 || policy == 2 || policy == 5))
+    return fail(LT_ERR_UNSUPPORTED, "shift policy %d is a tile variant of the experiments build (make EXPERIMENTS=1)", policy);
   if (p->shift != policy) p->canary = 0;
   p->shift = policy;
   return LT_OK;
@@ -1401,12 +1411,14 @@ int lt_plan_set_graph_mode(lt_plan *p, int32_t mode) {
   return LT_OK;
 }
 
+#if LT_EXPERIMENTS
 int lt_stream_collide_thrice(lt_plan *p, const void *f, void *out, double tau, void *stream) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (p->unit.d != 3 || p->desc.ghost_planes || p->masked || p->desc.layout != LT_LAYOUT_REFERENCE)
     return fail(LT_ERR_UNSUPPORTED, "three steps per launch: periodic 3-D plans without boundaries, reference layout");
   return step(p, lt::kFusedThrice, f, out, tau, 0, p->n2, stream);
 }
+#endif
 int lt_stream_collide_twice(lt_plan *p, const void *f, void *out, double tau, void *stream) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   const int g = p->desc.ghost_planes;
@@ -1671,6 +1683,17 @@ int lt_ipc_free(void *dev) {
   return LT_OK;
 }
 
+int lt_plan_set_arithmetic(lt_plan *p, int32_t mode) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (mode != 0 && mode != 1) return fail(LT_ERR_INVALID, "arithmetic %d (0 = the reference's, 1 = fast)", mode);
+  if (mode == 1 && (p->desc.collision != LT_COLLISION_BGK || p->unit.d != 3 || p->desc.n_boundaries > 0 || p->masked ||
+                    p->desc.layout != LT_LAYOUT_REFERENCE || p->desc.ghost_planes))
+    return fail(LT_ERR_UNSUPPORTED, "fast arithmetic exists for BGK on periodic 3-D plans without boundaries in the "
+                                    "reference layout");
+  p->arith = mode;
+  return LT_OK;
+}
+
 int lt_plan_set_canary(lt_plan *p, int32_t mode) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (mode < 0 || mode > 2) return fail(LT_ERR_INVALID, "canary mode %d (0 skip, 1 check on first use, 2 report a mismatch)", mode);
@@ -1697,6 +1720,9 @@ int lt_plan_set_residency(lt_plan *p, int32_t workgroups_per_cu) {
 int lt_plan_set_tuning(lt_plan *p, int32_t cache_policy, int32_t wide) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (cache_policy < -1 || cache_policy > 3) return fail(LT_ERR_INVALID, "cache policy %d", cache_policy);
+  if (wide && !LT_EXPERIMENTS)
+    return fail(LT_ERR_UNSUPPORTED, "the 16-byte variants of the one-step kernel belong to the experiments build "
+                                    "(make EXPERIMENTS=1; they measured 8-13 %% slower)");
   p->tune = cache_policy;
   p->want_wide = wide ? 1 : 0;
   return LT_OK;

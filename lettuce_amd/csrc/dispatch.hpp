@@ -2,6 +2,9 @@
 // per-(stencil, dtype) translation units that instantiate the kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#ifndef LT_EXPERIMENTS
+#define LT_EXPERIMENTS 0        // make EXPERIMENTS=1: also the kernels that lost their A/B (unit.inc)
+#endif
 #include <stdint.h>
 
 namespace lt {

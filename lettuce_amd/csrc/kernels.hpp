@@ -311,7 +311,8 @@ struct CascadeSum {
   T head = T(0), tail = T(0);
   template <int q>
   __device__ __forceinline__ void add(T v) {
-    if constexpr (q < 16) head += v; else tail += v;
+#pragma clang fp contract(off)
+    if constexpr (q < 16) head += v; else tail += v;      // (never fused with the product that made v)
   }
   __device__ __forceinline__ T result() const {
     if constexpr (Q > 16) return tail + head; else return head;
@@ -442,6 +443,87 @@ __device__ __forceinline__ void collide_bgk(T (&f)[S::Q][VEC], T tau_inv) {
   });
 }
 
+// BGK in "fast" arithmetic (COLL = 3; lt_plan_set_arithmetic): the same collision to rounding level instead of bit
+// for bit.  collide_bgk reproduces every rounding of the reference's whole-field torch operators (~290 vector
+// instructions per node: three IEEE divisions by rho, the exact-division emulation 28 times, no fused multiply-adds,
+// ATen's summation order); SURVEY.md 8(d) only asks for max |df| <= 1e-5 max |f| after 10 steps and the kinetic
+// energy to 1e-6 (10 steps) / 5e-5 (100 steps) in fp32.  Here: moments over opposite pairs, one reciprocal of rho,
+// cs^2 = 1/3, omega folded into the weights, everything contracted -- about half the instructions.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
+template <typename T, class S, int LAYOUT, int VEC, int k>
+__device__ __forceinline__ void collide_bgk_fast(T (&f)[S::Q][VEC], T omega) {
+  // explicit fused multiply-adds and no contraction by the compiler: every kernel this is inlined into (one-step,
+  // collide-only, two-step) then returns the same bits, whatever the surrounding code
+#pragma clang fp contract(off)
+  using M = MemMap<S, LAYOUT>;
+  T rho = T(0), j[3] = {T(0), T(0), T(0)};
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int o = S::OPP[q];
+    if constexpr (q == o) {
+      rho += f[q][k];
+    } else if constexpr (q < o) {
+      rho += f[q][k] + f[o][k];
+      add_momentum<S, LAYOUT, q>(j, f[q][k] - f[o][k]);
+    }
+  });
+  const T inv = fast_rcp(rho);
+  // The reference divides by 2 cs^2 ROUNDED to the working dtype (fp32: 0.6666667, 3e-8 too large), which gives its
+  // fp32 equilibrium a momentum deficit of 3e-8 and its kinetic energy a drift of -1.1e-7 per step against its fp64
+  // run.  To stay within 1e-6 of ITS fp32 energy series the velocity carries the same factor:
+  // u = RN(j / rho (1 - delta)), formed inside one fused multiply-add so that the half-ulp correction acts through
+  // the rounding of the product (on a rounded product it would always round away).  fp64: delta = 1e-16, no effect.
+  constexpr double delta = 1.5 * (double)(T)(2.0 * kCs2) - 1.0;
+  T u[3] = {T(0), T(0), T(0)};
+  static_for<S::D>([&](auto ac) {
+    constexpr int a = decltype(ac)::value;
+    const T plain = j[a] * inv;
+    u[a] = fma_t(j[a], inv, T(-delta) * plain);
+  });
+  T uu = u[M::memory(0)] * u[M::memory(0)];
+  if constexpr (S::D > 1) uu = fma_t(u[M::memory(1)], u[M::memory(1)], uu);
+  if constexpr (S::D > 2) uu = fma_t(u[M::memory(2)], u[M::memory(2)], uu);
+  const T c0 = fma_t(T(-1.5), uu, T(1)), keep = T(1) - omega, wr = omega * rho;
+  static_for<S::Q>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int o = S::OPP[q];
+    if constexpr (q == o) {
+      f[q][k] = fma_t(keep, f[q][k], (T(S::W[q]) * wr) * c0);
+    } else if constexpr (q < o) {
+      const T eu = dot_e<S, LAYOUT, q>(u);
+#ifndef LT_FAST_VARIANT
+#define LT_FAST_VARIANT 0
+#endif
+#if LT_FAST_VARIANT == 0
+      const T w = T(S::W[q]) * wr, wh = w * fma_t(T(4.5) * eu, eu, c0), t = (T(3) * w) * eu;
+      f[q][k] = fma_t(keep, f[q][k], wh + t);
+      f[o][k] = fma_t(keep, f[o][k], wh - t);
+#elif LT_FAST_VARIANT == 1
+      {
+#pragma clang fp contract(fast)
+        const T h = (T(4.5) * eu) * eu + c0, w = T(S::W[q]) * wr, t = (T(3) * w) * eu;
+        f[q][k] = keep * f[q][k] + (w * h + t);
+        f[o][k] = keep * f[o][k] + (w * h - t);
+      }
+#elif LT_FAST_VARIANT == 2
+      const T w = T(S::W[q]) * wr, h = fma_t(T(4.5) * eu, eu, c0), t = (T(3) * w) * eu;
+      f[q][k] = fma_t(keep, f[q][k], fma_t(w, h, t));
+      f[o][k] = fma_t(keep, f[o][k], fma_t(w, h, -t));
+#elif LT_FAST_VARIANT == 3
+      // omega w rho as literals times wr: no weight registers
+      const T h = fma_t(T(4.5) * eu, eu, c0), g = fma_t(T(3.0 * S::W[q]), eu, T(S::W[q]) * h), m = fma_t(T(-3.0 * S::W[q]), eu, T(S::W[q]) * h);
+      f[q][k] = fma_t(keep, f[q][k], wr * g);
+      f[o][k] = fma_t(keep, f[o][k], wr * m);
+#endif
+    }
+  });
+}
+
 // KBC.  The reference forms s(f) and s(feq) from the second moments m/rho of f and of feq
 // (lettuce/ext/_collision/kbc_collision.py:25-39 moments, :44-94 s_i), each s_i being rho times a
 // linear combination of the normalised moments -- i.e. a linear function of the populations -- and
@@ -483,6 +565,7 @@ struct KbcS {
 // s(g) for a population set given as g(q), from raw second moments (logical axes x, y, z)
 template <typename T, class S, class G>
 __device__ __forceinline__ KbcS<T, S> kbc_s(const G &g) {
+#pragma clang fp contract(off)
   T xx = T(0), yy = T(0), zz = T(0), xy = T(0), xz = T(0), yz = T(0);
   static_for<S::Q>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
@@ -530,8 +613,12 @@ __device__ __forceinline__ double kbc_ratio(double x, double y) { return x / y; 
 
 // f' = f - beta (2 ds + gamma dh), dh = f - feq - ds (kbc_collision.py:130-158), evaluated as
 // f - (beta gamma) (f - feq) - (beta (2 - gamma)) ds with the seven distinct ds values scaled once.
+// No contraction by the compiler anywhere in the collision (round 4): which multiply-adds hipcc fused depended on the
+// kernel the function was inlined into, so the fused, the collide-only, the many-step and the two-step KBC kernels
+// agreed at rounding level only.  The two multiply-adds worth an instruction are written as fma_t.
 template <typename T, class S, int LAYOUT, int VEC, int k>
 __device__ __forceinline__ void collide_kbc(T (&f)[S::Q][VEC], T beta, T inv_beta) {
+#pragma clang fp contract(off)
   static_assert(S::Q == 9 || S::Q == 27, "KBC exists for D2Q9 and D3Q27 only (kbc_collision.py:100-128)");
   T rho, j[3], u[3];
   moments<T, S, LAYOUT, VEC, k>(f, rho, j);
@@ -565,7 +652,7 @@ __device__ __forceinline__ void collide_kbc(T (&f)[S::Q][VEC], T beta, T inv_bet
     constexpr int q = decltype(qc)::value;
     constexpr int sg = KbcS<T, S>::template sign<q>();
     const T x = f[q][k] - feq[q];
-    const T y = f[q][k] - bg * x;
+    const T y = fma_t(-bg, x, f[q][k]);
     const T m = dsc.template magnitude<q>();
     f[q][k] = sg == 0 ? y : (sg > 0 ? y - m : y + m);
   });
@@ -841,6 +928,7 @@ __device__ __forceinline__ void lbm_body(const KParams<T> &p) {
       if (b == 0) {
         if constexpr (COLL == 1) collide_bgk<T, S, LAYOUT, VEC, k>(f, p.tau_inv);
         if constexpr (COLL == 2) collide_kbc<T, S, LAYOUT, VEC, k>(f, p.beta, p.inv_beta);
+        if constexpr (COLL == 3) collide_bgk_fast<T, S, LAYOUT, VEC, k>(f, p.tau_inv);
       }
       if constexpr (MASKED)
         apply_boundaries<T, S, LAYOUT, STREAM, VEC, k, COLL, ABBD>(p, b, c0 + k, c1, c2, own + k, f, lane_slot,
@@ -945,7 +1033,7 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
   static_assert(NI % NPT == 0 && NO % NPB == 0, "nodes per thread must divide the tile");
   constexpr int NU = B::template count<LAYOUT, 1>(), NC = B::template count<LAYOUT, 0>(),
                 ND = B::template count<LAYOUT, -1>();
-  static_assert(COLL == 0 || COLL == 1, "two-step kernel: streaming only or BGK");
+  static_assert(COLL == 0 || COLL == 1 || COLL == 3, "two-step kernel: streaming only or BGK (exact / fast arithmetic)");
   __shared__ T lds_u[4][NU][NI];
   __shared__ T lds_c[3][NC][NI];
   __shared__ T lds_d[2][ND][NI];
@@ -1071,6 +1159,8 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
     if (in_a) {
       if constexpr (COLL == 1)
         static_for<NPT>([&](auto kc) { collide_bgk<T, S, LAYOUT, NPT, decltype(kc)::value>(pre, p.tau_inv); });
+      if constexpr (COLL == 3)
+        static_for<NPT>([&](auto kc) { collide_bgk_fast<T, S, LAYOUT, NPT, decltype(kc)::value>(pre, p.tau_inv); });
       static_for<S::Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr int e2 = M::e(q, 2), rank = crossing_rank<S, LAYOUT, q>();
@@ -1103,6 +1193,8 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
     if (in_b) {
       if constexpr (COLL == 1)
         static_for<NPB>([&](auto kc) { collide_bgk<T, S, LAYOUT, NPB, decltype(kc)::value>(f, p.tau_inv); });
+      if constexpr (COLL == 3)
+        static_for<NPB>([&](auto kc) { collide_bgk_fast<T, S, LAYOUT, NPB, decltype(kc)::value>(f, p.tau_inv); });
     }
   };
   // packing: this workgroup writes halo messages (PACK kernels; a launch that covers a whole slab runs the

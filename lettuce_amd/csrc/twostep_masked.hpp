@@ -120,13 +120,9 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
                 ND = B::template count<LAYOUT, -1>();
   static_assert(COLL == 0 || COLL == 1 || COLL == 2, "two-step kernel: streaming only, BGK or (experiment) KBC");
   static_assert(NO % 64 == 0, "the output nodes of a tile fill whole waves");
-  // D3Q27: the collision + boundary code of one node is ~3000 instructions, and the sweep below inlines it fifteen
-  // times (three prologue planes, a peeled, a steady-state and a tail copy of the interval, for two wave roles):
-  // 300 KB of code against a 64 KB instruction cache shared by two compute units.  COMPACT keeps one copy of the
-  // prologue plane and one of the interval per role (the conditions of the tail are then tested in every interval):
-  // 105 KB -- and measured SLOWER (Obstacle D3Q27 256^3 BGK: 0.520 against 0.49 ms per update on the same box), so
-  // the instruction cache is not what holds this kernel back; kept as a switch for the record.
-  constexpr bool COMPACT = false;
+  // (D3Q27: the collision + boundary code of one node is ~3000 instructions and the sweep below inlines it fifteen
+  // times -- 300 KB of code against a 64 KB instruction cache.  A compact form with one copy of the prologue plane and
+  // one of the interval per role, 105 KB, measured 5 % SLOWER in round 3: the peeled steady-state loop earns its size.)
   __shared__ T lds_u[4][NU][NI];
   __shared__ T lds_c[3][NC][NI];
   __shared__ T lds_d[3][ND][NI];
@@ -395,14 +391,9 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
       load_a(s - 2);
       if (in_a) moments_for_outlet(pre, nd_pre, (unsigned)wrapped(s - 2) * plane_nodes + a_own, sa_rho, sa_j);
     }
-    if constexpr (COMPACT) {
-#pragma clang loop unroll(disable)
-      for (int i = 0; i < 3; ++i) { load_a(s - 1 + i); compute_a(i, i, s - 1 + i); }
-    } else {
-      load_a(s - 1); compute_a(0, 0, s - 1);
-      load_a(s);     compute_a(1, 1, s);
-      load_a(s + 1); compute_a(2, 2, s + 1);
-    }
+    load_a(s - 1); compute_a(0, 0, s - 1);
+    load_a(s);     compute_a(1, 1, s);
+    load_a(s + 1); compute_a(2, 2, s + 1);
     if constexpr (HAS_B) nd_b_next = p.node[(unsigned)s * plane_nodes + b_own];
     if (s + 2 <= last) load_a(s + 2);
     int r = 1, r3 = 1;                              // output plane k has relative index k - s + 1
@@ -427,11 +418,9 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
       r3 = r3 == 2 ? 0 : r3 + 1;
     };
     int k = s;
-    if constexpr (!COMPACT) {
-      if (last - s >= 4) {
-        interval(std::true_type{}, k++);            // peeled: see the header of this file
-        for (; k + 3 <= last; ++k) interval(std::true_type{}, k);
-      }
+    if (last - s >= 4) {
+      interval(std::true_type{}, k++);              // peeled: see the header of this file
+      for (; k + 3 <= last; ++k) interval(std::true_type{}, k);
     }
 #pragma clang loop unroll(disable)
     for (; k < last; ++k) interval(std::false_type{}, k);

@@ -31,7 +31,12 @@ def _engine_collide(flow, kind, tau):
 
 
 class BGKCollision(Collision):
-    """f - (f - feq(rho, u)) / tau (lettuce/ext/_collision/bgk_collision.py:12-35)."""
+    """f - (f - feq(rho, u)) / tau (lettuce/ext/_collision/bgk_collision.py:12-35).
+
+    ``arithmetic`` (an attribute, not part of the reference's signature): "exact" (default) -- the HIP engine reproduces
+    the reference's floating-point operations one for one; "fast" -- its shorter collision, equal to rounding level
+    (periodic 3-D flows; ``Simulation`` raises where the engine has no such kernel)."""
+    arithmetic = "exact"
 
     def __init__(self, tau, force: Optional["Force"] = None):
         self.tau = tau
@@ -58,7 +63,7 @@ class BGKCollision(Collision):
         return self.force is None
 
     def native_generator(self) -> "NativeCollision":
-        return NativeCollision("bgk", tau=lambda flow: self.tau)
+        return NativeCollision("bgk", tau=lambda flow: self.tau, arithmetic=getattr(self, "arithmetic", "exact"))
 
 
 class KBCCollision(Collision):

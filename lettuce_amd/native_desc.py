@@ -24,6 +24,10 @@ class NativeCollision:
     # reference re-reads collision.tau on every invocation
     # (lettuce/cuda_native/ext/_collision/bgk_collision.py:30)
     tau: Callable[["Flow"], float] = field(default=lambda flow: 1.0)
+    # "exact": the reference's floating-point operations one for one (the default; bit-identical periodic BGK flows);
+    # "fast": the engine's shorter BGK collision, equal to rounding level (lt_plan_set_arithmetic) -- opt-in through
+    # ``collision.arithmetic = "fast"``, never chosen by the engine
+    arithmetic: str = "exact"
 
 
 @dataclass

@@ -19,15 +19,30 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "experiments: exercises a kernel that lost its A/B and is only in the library when "
+                                       "it was built with `make -C lettuce_amd/csrc EXPERIMENTS=1`")
+
+
+def experiments_built() -> bool:
+    try:
+        from lettuce_amd import _native
+        return os.path.exists(_native.library_path()) and _native.experiments_built()
+    except Exception:
+        return False
 
 
 def pytest_collection_modifyitems(config, items):
-    if torch.cuda.is_available():
-        return
-    skip = pytest.mark.skip(reason="no GPU visible")
+    no_gpu = pytest.mark.skip(reason="no GPU visible")
+    no_experiments = pytest.mark.skip(reason="kernel of the experiments build (make EXPERIMENTS=1)")
+    have_gpu, have_experiments = torch.cuda.is_available(), None
     for item in items:
-        if "gpu" in item.keywords:
-            item.add_marker(skip)
+        if "gpu" in item.keywords and not have_gpu:
+            item.add_marker(no_gpu)
+        if "experiments" in item.keywords:
+            if have_experiments is None:
+                have_experiments = experiments_built()
+            if not have_experiments:
+                item.add_marker(no_experiments)
 
 
 def golden(name):

@@ -255,11 +255,16 @@ def test_torch_gradient_orders():
 def test_library_exports_every_declared_symbol(engine_library):
     from lettuce_amd import _native
     header = open(os.path.join(ROOT, "include", "lettuce_hip.h")).read()
-    declared = set(re.findall(r"\b(lt_[a-z_]+)\s*\(", header))
+    # entry points of the kernels that lost their A/B are declared under LT_EXPERIMENTS and exist only in a library
+    # built with `make EXPERIMENTS=1` (lt_build_flags() & 1)
+    experiments = "".join(re.findall(r"#ifdef LT_EXPERIMENTS\n(.*?)#endif", header, re.S))
+    declared = set(re.findall(r"\b(lt_[a-z_]+)\s*\(", header.replace(experiments, "")))
     assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
+    assert set(re.findall(r"\b(lt_[a-z_]+)\s*\(", experiments)) == set(_native.EXPERIMENT_SYMBOLS)
     lib = _native.load_library()
-    for name in declared:
+    for name in declared | (set(_native.EXPERIMENT_SYMBOLS) if lib.lt_build_flags() & 1 else set()):
         assert hasattr(lib, name), name
+    assert not (lib.lt_build_flags() & 1) or _native.experiments_built()
     assert lib.lt_abi_version() == 1
     # argument checks that run before any HIP call
     bad = _native._PlanDesc()

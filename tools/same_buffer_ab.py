@@ -35,6 +35,8 @@ def plan_from(path):
         plan.set_population_stride(-(-(384 * 384 * 96 + 32832) // 64) * 64)
         return plan
     plan = nat.Plan("D3Q19", torch.float32, "bgk", [256, 256, 256], [], device=dev)
+    if os.environ.get("LT_AB_ARITH"):                # "fast": A/B of variants of the fast BGK arithmetic
+        plan.set_arithmetic(os.environ["LT_AB_ARITH"])
     plan.set_two_step(1, 0)
     plan.set_population_stride(-(-(256 ** 3 + 32832) // 64) * 64)
     return plan
@@ -52,7 +54,7 @@ for trial in range(2):                       # two sets of buffers
         if ref is None:
             ref = g.clone()
         elif not torch.equal(g, ref):
-            print(json.dumps({"lib": name, "MISMATCH": True}))
+            print(json.dumps({"lib": name, "MISMATCH": True, "max_abs_diff": float((g - ref).abs().max())}))
     del ref
     times = {name: [] for name in libs}
     for rep in range(5):
