@@ -129,6 +129,10 @@ def parse(argv=None):
     ap.add_argument("--watchdog-grace", type=float, default=60.0,
                     help="slab path: seconds past a candidate's budget after which the watchdog prints the held line "
                          "and ends the rank")
+    ap.add_argument("--hang-exit-code", type=int, default=int(os.environ.get("LT_BENCH_HANG_EXIT_CODE", "0")),
+                    help="slab path: exit code of a rank whose candidate call never returned, after the held line of an "
+                         "earlier candidate has been printed (default 0: the line is a complete measurement; the hang is "
+                         "recorded in config.transport.aborted and on stderr)")
     ap.add_argument("--slab", action="store_true",
                     help="use the z-slab driver (and an RCCL process group) even with one GPU: "
                          "rehearsal of the N > 1 code path")
@@ -403,6 +407,9 @@ def other_configs(lt, device):
 
 
 # ---- the held line of the N > 1 path ----------------------------------------------------------
+HANG_EXIT_CODE = 0
+
+
 class HeldLine:
     """The line rank 0 will print, replaced only by better candidates; a watchdog prints it and ends the rank when
     a candidate call does not return."""
@@ -416,7 +423,11 @@ class HeldLine:
         self._thread.start()
 
     def arm(self, seconds, what):
-        self.deadline, self.what = time.time() + seconds, what
+        self.deadline, self.what, self.phase = time.time() + seconds, what, "set-up"
+
+    def at(self, phase):
+        """which call of the candidate is in flight (for the watchdog's diagnostic)"""
+        self.phase = phase
 
     def disarm(self):
         self.deadline = None
@@ -444,13 +455,20 @@ class HeldLine:
             d = self.deadline
             if d is None or time.time() <= d:
                 continue
+            where = f"{self.what} ({getattr(self, 'phase', '?')})"
+            sys.stderr.write(f"bench.py: rank {self.rank}: a call of candidate {where} did not return within its budget: "
+                             f"a GPU or RCCL call is stuck; the rank ends itself\n")
+            sys.stderr.flush()
             if self.line is not None:
-                self.line["config"]["transport"]["aborted"] = f"{self.what}: no return within its budget; held line printed by the watchdog"
+                self.line["config"]["transport"]["aborted"] = f"{where}: no return within its budget; held line printed by the watchdog"
                 self.emit()
-                os._exit(0)
+                # the held line is a complete, verified measurement of an earlier candidate: by default the job still
+                # counts as run (exit code 0, the hang is in config.transport.aborted and on stderr);
+                # --hang-exit-code N makes the hang visible to a harness that only looks at exit codes
+                os._exit(HANG_EXIT_CODE)
             # the reference candidate itself never came back: end the rank (every rank has the same deadline) rather
             # than hang until the caller's limit
-            self.emit_nothing(f"{self.what}: no return within its budget and no line held; ended by the watchdog")
+            self.emit_nothing(f"{where}: no return within its budget and no line held; ended by the watchdog")
             os._exit(3)
 
 
@@ -775,6 +793,8 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
                                          "aborted": why}},
                 "roofline": None, "cpu_baseline": cpu_baseline_row, "verified": None}
 
+    global HANG_EXIT_CODE
+    HANG_EXIT_CODE = int(getattr(args, "hang_exit_code", 0))
     held = HeldLine(rank, nothing_held)
     seen = seen_box["seen"] = ranks.devices()             # collective: before any candidate
     reference = {}                     # the first candidate's populations after the probe and after its timed batches
@@ -868,7 +888,9 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
             # ---- build + connection set-up ----
             cand, err = None, None
             try:
+                held.at("build")
                 cand = build(driver, transport)
+                held.at("first three steps (connection set-up)")
                 cand(3)                         # connection set-up, first launches: not timed
             except Exception as exc:            # unsupported grid for the two-step kernel, no symmetric memory ...
                 err = f"unavailable: {type(exc).__name__}: {str(exc)[:120]}"
@@ -879,7 +901,8 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
                 continue
             # ---- warm-up probe: two batches of >= 60 steps, the faster one counts ----
             best, err = None, None
-            for _ in range(2):
+            for probe_round in range(2):
+                held.at(f"warm-up probe {probe_round + 1} of 2")
                 barrier()
                 t0 = time.perf_counter()
                 try:
@@ -919,7 +942,8 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
             # after the timed batches can be compared too
             repeat = reference.get("repeat") or repeats_for(max_over_ranks(time.perf_counter() - t0))
             batch_s, err = [], None
-            for _ in range(max(1, args.batches)):
+            for batch in range(max(1, args.batches)):
+                held.at(f"timed batch {batch + 1} of {max(1, args.batches)}")
                 barrier()
                 t0 = time.perf_counter()
                 try:

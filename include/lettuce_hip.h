@@ -324,6 +324,10 @@ const char *lt_plan_kernel_name(lt_plan *plan);
  * the slab edge launch (two workgroups per CU; measured slower: 99 against 77 us).  1, 2 and 5 are tile variants
  * that lost their A/B: they exist in the experiments build only (LT_ERR_UNSUPPORTED otherwise). */
 int lt_plan_set_shift_policy(lt_plan *plan, int32_t policy);
+/* out[i] = x[i] / D as the kernels' equilibrium forms it (div_cs: two or three instructions that return the IEEE
+ * quotient by the constant D = 2 cs^2 (which 0) or cs^2 (which 1) rounded to dtype, the reference's divisors:
+ * lettuce/ext/_equilibrium/quadratic_equilibrium.py:15-24) -- a test hook that pins the emulation on the device. */
+int lt_probe_div_cs(const void *x_dev, void *out_dev, int64_t n, int32_t dtype, int32_t which, void *stream);
 /* Diagnostic: dst[0:n_bytes] = src[0:n_bytes] with 16-byte accesses and the cache-policy bits of
  * lt_plan_set_tuning; max_blocks > 0 caps its grid (grid-stride loop).  bench.py uses it to
  * measure this device's copy ceiling. */

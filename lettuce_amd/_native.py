@@ -123,6 +123,7 @@ SYMBOLS = {
     "lt_stream_collide_many": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _i32, _vp]),
     "lt_plan_set_many_step": (ctypes.c_int, [_vp, _i32]),
     "lt_probe_copy": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "lt_probe_div_cs": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "lt_ipc_alloc": (ctypes.c_int, [_i64, ctypes.POINTER(_vp), ctypes.c_char_p]),
     "lt_ipc_open": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_vp)]),
     "lt_ipc_close": (ctypes.c_int, [_vp]),
@@ -221,6 +222,16 @@ def probe_copy(dst: torch.Tensor, src: torch.Tensor, cache_policy: int = 0, max_
         raise NativeEngineError(lib.lt_last_error().decode())
 
 
+def probe_div_cs(x: torch.Tensor, which: int) -> torch.Tensor:
+    """x / (2 cs^2) (which 0) or x / cs^2 (which 1) with the kernels' exact-division emulation (test hook)"""
+    lib = load_library()
+    out = torch.empty_like(x)
+    code = lib.lt_probe_div_cs(_ptr(x), _ptr(out), x.numel(), DTYPE_IDS[x.dtype], int(which), _stream_handle())
+    if code != 0:
+        raise NativeEngineError(lib.lt_last_error().decode())
+    return out
+
+
 class Plan:
     """One engine configuration: lattice x dtype x collision x grid (x boundaries).
 
@@ -256,6 +267,7 @@ class Plan:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self._keepalive = {}            # boundary index -> field tensor the engine holds a pointer to
         self._const = {}                # answers of the engine that do not change while the masks stay
+        self.resident_mode = -1         # lt_plan_set_resident: -1 automatic, 0 off, 1 requested
         self.pop_stride = 0             # elements between populations of the caller's buffers (0 = dense)
         desc = _PlanDesc()
         desc.abi_version = LT_ABI_VERSION
@@ -301,7 +313,9 @@ class Plan:
     def _check(self, code: int):
         if code != 0:
             msg = self.lib.lt_last_error().decode("utf-8", "replace")
-            raise NativeEngineError(f"HIP engine error {code}: {msg}")
+            exc = NativeEngineError(f"HIP engine error {code}: {msg}")
+            exc.code = code                                  # LT_ERR_* (4 = LT_ERR_ALLOC)
+            raise exc
 
     def _tensor_ok(self, t: torch.Tensor, shape=None):
         if t.device.type != "cuda":
@@ -506,6 +520,7 @@ class Plan:
     def set_resident(self, mode: int = -1, pad_elements: int = -1):
         """engine-owned padded buffers for the fused steps: -1 automatic, 0 off, 1 on"""
         self._check(self.lib.lt_plan_set_resident(self._handle, int(mode), int(pad_elements)))
+        self.resident_mode = int(mode)
 
     @_on_device
     def resident_enabled(self):
@@ -516,8 +531,15 @@ class Plan:
 
     @_on_device
     def resident_load(self, f, tau):
+        """collide pass from the caller's dense populations into the engine's padded buffers, which are allocated
+        here on first use (raw hipMalloc: two more population fields).  If that fails, memory torch merely caches is
+        returned to the driver and the allocation tried once more."""
         self._tensor_ok(f, self.f_shape)
-        self._check(self.lib.lt_resident_load(self._handle, _ptr(f), float(tau), _stream_handle()))
+        code = self.lib.lt_resident_load(self._handle, _ptr(f), float(tau), _stream_handle())
+        if code == 4:                                        # LT_ERR_ALLOC
+            torch.cuda.empty_cache()
+            code = self.lib.lt_resident_load(self._handle, _ptr(f), float(tau), _stream_handle())
+        self._check(code)
 
     @_on_device
     def resident_advance(self, tau, n_steps):

@@ -192,7 +192,17 @@ class _NativeStepper:
         self._sync_boundaries()
         tau = float(self.collision.tau(flow))
         if self.plan.resident_enabled()[0]:
-            return self._batch_resident(k, tau)
+            try:
+                return self._batch_resident(k, tau)
+            except NativeEngineError as exc:
+                # the engine's own padded buffers could not be allocated (two more population fields, raw
+                # hipMalloc; torch's cache was emptied and the allocation tried again).  "Automatic" then carries on
+                # with the caller's dense tensors; a plan on which resident populations were REQUESTED keeps the error
+                if getattr(exc, "code", None) != 4 or self.plan.resident_mode == 1:
+                    raise
+                warnings.warn(f"resident populations unavailable ({exc}); stepping on flow.f / flow.f_next", stacklevel=3)
+                self.plan.set_resident(0)
+                self._carry = None
         changed = self._carry is None                         # first batch, or masks / boundaries were replaced
         pending = flow._pending is not None and self._lazy is not None
         if pending:
@@ -265,6 +275,7 @@ class _NativeStepper:
         def drop():                                           # flow.f was assigned while the pass was pending
             self._lazy = None
             self._carry = None
+            plan.resident_free()                              # the state they held is void: give the two fields back
         finish.drop = drop
         flow._pending = finish
 

@@ -87,6 +87,15 @@ __global__ void write_flag_kernel(unsigned long long *flag, unsigned long long v
   __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// the equilibrium's exact division by its rounded constants (kernels.hpp, div_cs) on an array: the GPU-side pin of
+// what tests/aux/exact_division_check.c proves on the host -- in particular that the device keeps fp32 denormals
+// (x r_lo of the two-instruction form is denormal for |x / D| below ~1e-30)
+template <typename T>
+__global__ void __launch_bounds__(256) probe_div_cs_kernel(const T *x, T *out, long long n, int which) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = which == 0 ? lt::div_cs<0>(x[i]) : lt::div_cs<1>(x[i]);
+}
+
 // first-use check of the masked two-step kernels (run_canary): synthetic populations -- positive, near 1 / Q, a
 // different value in nearly every slot -- and a bit-for-bit comparison of two population fields over a plane range
 template <typename T>
@@ -1307,6 +1316,19 @@ int lt_probe_copy(void *dst, const void *src, int64_t n_bytes, int32_t cache_pol
     case 3: hipLaunchKernelGGL(probe_copy_kernel<3>, dim3((unsigned)grid), dim3(256), 0, s, sp, dp, n); break;
     default: return fail(LT_ERR_INVALID, "cache policy %d", cache_policy);
   }
+  LT_HIP(hipGetLastError());
+  return LT_OK;
+}
+
+int lt_probe_div_cs(const void *x, void *out, int64_t n, int32_t dtype, int32_t which, void *stream) {
+  if (!x || !out || n < 1 || (which != 0 && which != 1) || (dtype != LT_F32 && dtype != LT_F64))
+    return fail(LT_ERR_INVALID, "probe_div_cs: null buffer, n = %lld, which = %d, dtype = %d", (long long)n, which, dtype);
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == LT_F32)
+    hipLaunchKernelGGL(probe_div_cs_kernel<float>, dim3(grid), dim3(256), 0, s, (const float *)x, (float *)out, (long long)n, which);
+  else
+    hipLaunchKernelGGL(probe_div_cs_kernel<double>, dim3(grid), dim3(256), 0, s, (const double *)x, (double *)out, (long long)n, which);
   LT_HIP(hipGetLastError());
   return LT_OK;
 }

@@ -875,6 +875,35 @@ def test_cfg1_populations_bit_identical_after_100_steps():
     np.testing.assert_array_equal(run_engine(plan, g["f0"], float(g["tau"]), 100), g["f100"])
 
 
+# --------------------------------------------------------------------------- exact division on the device
+@pytest.mark.parametrize("dt,which", [("f32", 0), ("f32", 1), ("f64", 0), ("f64", 1)])
+def test_exact_division_emulation_on_the_device(dt, which):
+    """div_cs on the GPU against IEEE division by the reference's rounded constant, bit for bit, on a stratified
+    sample of bit patterns: every binade from 1e-30 |x / D| up to 1e30 (the range the host-side exhaustive check
+    covers, tests/aux/exact_division_check.c) plus random mantissas -- which needs fp32 denormals to survive v_mul /
+    v_fma (x r_lo is denormal near the lower end).  Below the cut-off the emulation may differ from the
+    quotient; the result must still be finite and within 2 ulp."""
+    from lettuce_amd._native import probe_div_cs
+    ftype, itype = (np.float32, np.uint32) if dt == "f32" else (np.float64, np.uint64)
+    d = ftype((2.0 if which == 0 else 1.0) * orc.CS2) if hasattr(orc, "CS2") else ftype((2.0 if which == 0 else 1.0) * (1 / np.sqrt(3.0)) ** 2)
+    rng = np.random.default_rng(5)
+    mant_bits, bias = (23, 127) if dt == "f32" else (52, 1023)
+    lo, hi = (-100, 100) if dt == "f32" else (-1000, 1000)          # exponents: 1e-30 .. 1e30 / 1e-301 .. 1e301
+    exps = np.arange(lo, hi + 1)
+    mant = rng.integers(0, 1 << mant_bits, size=(len(exps), 4096), dtype=np.uint64)
+    mant[:, :8] = [0, 1, 2, (1 << mant_bits) - 1, (1 << mant_bits) - 2, 1 << (mant_bits - 1), (1 << (mant_bits - 1)) - 1, 3]
+    bits = ((exps[:, None] + bias).astype(np.uint64) << np.uint64(mant_bits)) | mant
+    x = np.concatenate([bits.astype(itype).view(ftype).ravel(), -bits.astype(itype).view(ftype).ravel()])
+    got = probe_div_cs(dev(x), which).cpu().numpy()
+    want = (x / d).astype(ftype)
+    np.testing.assert_array_equal(got.view(itype), want.view(itype))
+    # below the cut-off: tiny arguments down to the smallest normals
+    tiny = (ftype(1e-37) if dt == "f32" else ftype(1e-307)) * (1 + rng.random(4096).astype(ftype))
+    g = probe_div_cs(dev(tiny), which).cpu().numpy()
+    w = (tiny / d).astype(ftype)
+    assert np.isfinite(g).all() and (np.abs(g - w) <= 2 * np.spacing(w)).all()
+
+
 # --------------------------------------------------------------------------- KBC: one arithmetic in every kernel
 @pytest.mark.parametrize("lat,res,dt", [("D3Q27", [8, 8, 64], "f32"), ("D3Q27", [6, 10, 12], "f64"), ("D2Q9", [64, 48], "f32"),
                                         ("D2Q9", [16, 24], "f64")])
