@@ -496,30 +496,14 @@ __device__ __forceinline__ void collide_bgk_fast(T (&f)[S::Q][VEC], T omega) {
       f[q][k] = fma_t(keep, f[q][k], (T(S::W[q]) * wr) * c0);
     } else if constexpr (q < o) {
       const T eu = dot_e<S, LAYOUT, q>(u);
-#ifndef LT_FAST_VARIANT
-#define LT_FAST_VARIANT 0
-#endif
-#if LT_FAST_VARIANT == 0
-      const T w = T(S::W[q]) * wr, wh = w * fma_t(T(4.5) * eu, eu, c0), t = (T(3) * w) * eu;
-      f[q][k] = fma_t(keep, f[q][k], wh + t);
-      f[o][k] = fma_t(keep, f[o][k], wh - t);
-#elif LT_FAST_VARIANT == 1
-      {
-#pragma clang fp contract(fast)
-        const T h = (T(4.5) * eu) * eu + c0, w = T(S::W[q]) * wr, t = (T(3) * w) * eu;
-        f[q][k] = keep * f[q][k] + (w * h + t);
-        f[o][k] = keep * f[o][k] + (w * h - t);
-      }
-#elif LT_FAST_VARIANT == 2
-      const T w = T(S::W[q]) * wr, h = fma_t(T(4.5) * eu, eu, c0), t = (T(3) * w) * eu;
-      f[q][k] = fma_t(keep, f[q][k], fma_t(w, h, t));
-      f[o][k] = fma_t(keep, f[o][k], fma_t(w, h, -t));
-#elif LT_FAST_VARIANT == 3
-      // omega w rho as literals times wr: no weight registers
-      const T h = fma_t(T(4.5) * eu, eu, c0), g = fma_t(T(3.0 * S::W[q]), eu, T(S::W[q]) * h), m = fma_t(T(-3.0 * S::W[q]), eu, T(S::W[q]) * h);
+      // the weights as literals: w h +- 3 w (e.u) with h = 1 - 1.5 u.u + 4.5 (e.u)^2, then omega rho once.  Measured on
+      // the same buffers against three other arrangements of the same multiply-adds (weights times omega rho in
+      // registers; sums fused the other way round; the compiler's own contraction): 0.4749 against 0.4771 - 0.4845 ms
+      // per launch at 256^3, the exact arithmetic 0.496 - 0.516 (profiles/r04j_fast_arithmetic_variants.jsonl)
+      const T h = fma_t(T(4.5) * eu, eu, c0);
+      const T g = fma_t(T(3.0 * S::W[q]), eu, T(S::W[q]) * h), m = fma_t(T(-3.0 * S::W[q]), eu, T(S::W[q]) * h);
       f[q][k] = fma_t(keep, f[q][k], wr * g);
       f[o][k] = fma_t(keep, f[o][k], wr * m);
-#endif
     }
   });
 }
