@@ -379,6 +379,9 @@ def other_configs(lt, device):
     del sim, flow, start, two
     torch.cuda.empty_cache()
 
+    from lettuce_amd._native import experiments_built
+    if not experiments_built():
+        return rows
     # cfg2 again with the BGK collision in fast arithmetic (opt-in: collision.arithmetic = "fast"; the headline line
     # above is the exact arithmetic, bit-identical to the reference's CPU path)
     ctx = lt.Context(device=device, dtype=torch.float32, use_native=True)

@@ -427,7 +427,10 @@ int lt_plan_last_run_info(lt_plan *plan, int64_t *single_step_launches, int64_t 
  * them): -1 = automatic (3, or 4 for fp32 KBC, once the populations stream from HBM and the launch
  * fills the chip several times over; no cap otherwise), 0 = no cap, 2..8 = that many. */
 int lt_plan_set_residency(lt_plan *plan, int32_t workgroups_per_cu);
-/* Arithmetic of the BGK collision.  0 (default) = the reference's, operation for operation: every rounding of
+#ifdef LT_EXPERIMENTS
+/* (experiments build only: 4-7 % faster than the exact arithmetic where <= 0.45 ms per launch had been the bar, and
+ * 1.0-1.5e-6 off the reference's fp32 kinetic energy after 10 steps where SURVEY 8(d) states 1e-6 -- DESIGN.md section 4)
+ * Arithmetic of the BGK collision.  0 (default) = the reference's, operation for operation: every rounding of
  * lettuce's whole-field torch operators is reproduced (ATen's summation order, u = j / rho by IEEE division, the
  * division by the rounded constants 2 cs^2 and cs^2, no fused multiply-adds; lettuce/_flow.py:136-172,
  * ext/_equilibrium/quadratic_equilibrium.py:11-25, ext/_collision/bgk_collision.py:17-22), so periodic BGK flows are
@@ -437,6 +440,7 @@ int lt_plan_set_residency(lt_plan *plan, int32_t workgroups_per_cu);
  * over 10 / 100 steps) but NOT bit-identical to the reference; exists for BGK on periodic 3-D plans without
  * boundaries in the reference layout, never chosen by the engine itself. */
 int lt_plan_set_arithmetic(lt_plan *plan, int32_t mode);
+#endif
 /* First-use check of the two-step kernels of a plan WITH masks.  Before such a plan uses a two-step kernel for the
  * first time (lt_run's pairs, lt_resident_advance, every lt_stream_collide_twice* entry point,
  * lt_plan_two_step_admitted), one double step over all its planes is held against two one-step launches: synthetic

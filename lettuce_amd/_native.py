@@ -131,7 +131,6 @@ SYMBOLS = {
     "lt_halo_copy": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, ctypes.POINTER(_i32)]),
     "lt_flag_write": (ctypes.c_int, [_vp, ctypes.c_uint64, _i32, _vp]),
     "lt_flag_wait": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp, _vp]),
-    "lt_plan_set_arithmetic": (ctypes.c_int, [_vp, _i32]),
     "lt_plan_set_canary": (ctypes.c_int, [_vp, _i32]),
     "lt_plan_canary_status": (ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_char_p)]),
 }
@@ -139,6 +138,7 @@ SYMBOLS = {
 # entry points of the experiments build (make -C lettuce_amd/csrc EXPERIMENTS=1): bound when the library has them
 EXPERIMENT_SYMBOLS = {
     "lt_stream_collide_thrice": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _vp]),
+    "lt_plan_set_arithmetic": (ctypes.c_int, [_vp, _i32]),
 }
 
 _LIB = None
@@ -789,6 +789,11 @@ class Plan:
         """"exact" / 0: the reference's arithmetic operation for operation (bit-identical periodic BGK flows);
         "fast" / 1: the same collision to rounding level in half the instructions (BGK, periodic 3-D plans)"""
         mode = {"exact": 0, "fast": 1}.get(mode, mode)
+        if not experiments_built():
+            if int(mode) == 0:
+                return
+            raise NativeEngineError("fast arithmetic: a kernel of the experiments build (make -C lettuce_amd/csrc "
+                                    "EXPERIMENTS=1): it missed its bar (DESIGN.md section 4)")
         self._check(self.lib.lt_plan_set_arithmetic(self._handle, int(mode)))
 
     def set_canary(self, mode: int = 1):

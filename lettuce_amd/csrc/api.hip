@@ -1705,6 +1705,7 @@ int lt_ipc_free(void *dev) {
   return LT_OK;
 }
 
+#if LT_EXPERIMENTS
 int lt_plan_set_arithmetic(lt_plan *p, int32_t mode) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
   if (mode != 0 && mode != 1) return fail(LT_ERR_INVALID, "arithmetic %d (0 = the reference's, 1 = fast)", mode);
@@ -1715,6 +1716,8 @@ int lt_plan_set_arithmetic(lt_plan *p, int32_t mode) {
   p->arith = mode;
   return LT_OK;
 }
+
+#endif
 
 int lt_plan_set_canary(lt_plan *p, int32_t mode) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
