@@ -463,15 +463,16 @@ int lt_plan_canary_status(lt_plan *plan, int32_t *status_out, int64_t *mismatche
  * kernel of 64 workgroups and 20 KB of LDS each, which cannot share a compute unit with a 150 KB sweep workgroup and
  * costs the sweep beside it about 5 %; a device-to-device copy handed to a copy (SDMA) engine needs neither.
  *   lt_ipc_alloc / lt_ipc_open / lt_ipc_close / lt_ipc_free   device memory the other processes of the node can map:
- *       every rank allocates its receive window (halo messages + one 64-bit arrival counter per direction), sends the
- *       64-byte handle to its two z-neighbours through the process group and opens theirs;
+ *       every rank allocates its receive window (halo messages) and, as fine-grained memory (fine_grained = 1:
+ *       coherent with writers outside the running kernel), one 64-bit arrival counter per direction; it sends the
+ *       64-byte handles to its two z-neighbours through the process group and opens theirs;
  *   lt_halo_copy   dst <- src on `stream`; engine 1 = without compute units (hipMemcpyDeviceToDeviceNoCU: an SDMA
  *       engine, over xGMI when dst is a neighbour's window), 0 = the runtime's choice; *engine_used reports which;
  *   lt_flag_write  *flag <- value in stream order after the copies: how 1 = stream memory operation (command
  *       processor, no kernel), 0 = a one-thread kernel storing at system scope;
  *   lt_flag_wait   one wave that returns when *flag >= at_least or, after about a second, sets *timed_out_dev and
  *       returns all the same (the driver raises at the end of the batch; nothing traps, nothing spins for ever). */
-int lt_ipc_alloc(int64_t n_bytes, void **dev_out, void *handle_out_64_bytes);
+int lt_ipc_alloc(int64_t n_bytes, int32_t fine_grained, void **dev_out, void *handle_out_64_bytes);
 int lt_ipc_open(const void *handle_64_bytes, void **dev_out);
 int lt_ipc_close(void *mapped_dev);
 int lt_ipc_free(void *dev);

@@ -124,7 +124,7 @@ SYMBOLS = {
     "lt_plan_set_many_step": (ctypes.c_int, [_vp, _i32]),
     "lt_probe_copy": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "lt_probe_div_cs": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
-    "lt_ipc_alloc": (ctypes.c_int, [_i64, ctypes.POINTER(_vp), ctypes.c_char_p]),
+    "lt_ipc_alloc": (ctypes.c_int, [_i64, _i32, ctypes.POINTER(_vp), ctypes.c_char_p]),
     "lt_ipc_open": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_vp)]),
     "lt_ipc_close": (ctypes.c_int, [_vp]),
     "lt_ipc_free": (ctypes.c_int, [_vp]),

@@ -188,8 +188,9 @@ class _CopyWindow:
     """Receive windows for the halo transport that needs no compute unit (``transport="copy"``).
 
     Every rank allocates one block of device memory the other processes of the node can map (``lt_ipc_alloc``):
-    2 parities x 2 directions of halo messages, one 64-bit arrival counter per direction and a time-out word.  The
-    ranks exchange the 64-byte handles through the process group and open those of their two z-neighbours.  An
+    2 parities x 2 directions of halo messages, and -- in fine-grained memory -- one 64-bit arrival counter per
+    direction and a time-out word.  The ranks exchange the 64-byte handles through the process group and open those
+    of their two z-neighbours.  An
     exchange is then, on the sender's side: two device-to-device copies WITHOUT compute units (``lt_halo_copy``: an
     SDMA engine, over xGMI) from the buffers the edge launch wrote into the neighbours' windows, each followed by
     the write of the exchange counter into the neighbour's arrival word (``lt_flag_write``: a stream memory
@@ -220,39 +221,45 @@ class _CopyWindow:
         esize = torch.empty((), dtype=dtype).element_size()
         self.msg_bytes = int(np.prod(self.shape)) * esize
         self.msg_stride = -(-self.msg_bytes // 256) * 256
-        self.flag_offset = 4 * self.msg_stride
-        total = self.flag_offset + 256
-        base, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
-        self._torch_backing = None
-        if slab.world_size == 1 and os.environ.get("LT_SLAB_WINDOW_TORCH") == "1":
-            # experiment: the window of a rank that is its own neighbour needs no export; take it from torch's allocator
-            self._torch_backing = torch.zeros(total, dtype=torch.uint8, device=self.device)
-            base = ctypes.c_void_p(self._torch_backing.data_ptr())
-        else:
-            with torch.cuda.device(self.device):
-                self._check(self.lib.lt_ipc_alloc(total, ctypes.byref(base), handle))
-        self.base = int(base.value)
+        total = 4 * self.msg_stride
         self._opened = []
+
+        def allocate(n_bytes, fine):
+            base, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+            with torch.cuda.device(self.device):
+                code = self.lib.lt_ipc_alloc(n_bytes, int(fine), ctypes.byref(base), handle)
+                if code != 0 and fine:                    # no fine-grained memory to be had: ordinary memory
+                    code = self.lib.lt_ipc_alloc(n_bytes, 0, ctypes.byref(base), handle)
+                self._check(code)
+            return int(base.value), bytes(handle.raw)
+        # the messages, and -- in memory that stays coherent with a writer outside the running kernel -- the arrival
+        # counters (2 x 8 bytes) and the time-out word
+        self.base, data_handle = allocate(total, False)
+        self.flags, flag_handle = allocate(256, True)
         if slab.world_size == 1:
             self.at_prev = self.at_next = self.base          # my own neighbour: no mapping needed
+            self.flags_prev = self.flags_next = self.flags
         else:
             # (nobody writes into a window before its owner has zeroed it: lt_ipc_alloc does so, synchronously, before
-            # the handle is published)
+            # the handles are published)
             handles = [None] * slab.world_size
-            dist.all_gather_object(handles, bytes(handle.raw), group=group)
+            dist.all_gather_object(handles, (data_handle, flag_handle), group=group)
 
-            def mapped(rank):
+            def mapped(handle):
                 out = ctypes.c_void_p()
                 with torch.cuda.device(self.device):
-                    self._check(self.lib.lt_ipc_open(handles[rank], ctypes.byref(out)))
+                    self._check(self.lib.lt_ipc_open(handle, ctypes.byref(out)))
                 self._opened.append(int(out.value))
                 return int(out.value)
-            self.at_prev = mapped(slab.prev)
-            self.at_next = self.at_prev if slab.next == slab.prev else mapped(slab.next)
+            self.at_prev, self.flags_prev = mapped(handles[slab.prev][0]), mapped(handles[slab.prev][1])
+            if slab.next == slab.prev:
+                self.at_next, self.flags_next = self.at_prev, self.flags_prev
+            else:
+                self.at_next, self.flags_next = mapped(handles[slab.next][0]), mapped(handles[slab.next][1])
         typestr = {torch.float32: "<f4", torch.float64: "<f8"}[dtype]
         self._local = [[torch.as_tensor(_DevicePointer(self.base + (2 * p + d) * self.msg_stride, self.shape, typestr),
                                         device=self.device) for d in (0, 1)] for p in (0, 1)]
-        self._timed_out = torch.as_tensor(_DevicePointer(self.base + self.flag_offset + 64, (1,), "<i4"), device=self.device)
+        self._timed_out = torch.as_tensor(_DevicePointer(self.flags + 64, (1,), "<i4"), device=self.device)
         self.count = 0
         self.engines_used = set()
         # Both directions on the communication stream by default.  A stream of their own each lets two copy engines
@@ -279,7 +286,8 @@ class _CopyWindow:
         ready = torch.cuda.Event()
         ready.record(cur)
         used = ctypes.c_int32(0)
-        for side, (base, d, msg) in zip(self._streams, ((self.at_prev, 1, send_down), (self.at_next, 0, send_up))):
+        for side, (base, flags, d, msg) in zip(self._streams, ((self.at_prev, self.flags_prev, 1, send_down),
+                                                               (self.at_next, self.flags_next, 0, send_up))):
             if side is None:
                 side = cur
             else:
@@ -289,8 +297,7 @@ class _CopyWindow:
                                               ctypes.c_void_p(msg.data_ptr()), self.msg_bytes, self.engine, stream,
                                               ctypes.byref(used)))
             self.engines_used.add("copy engine (no compute units)" if used.value else "runtime's device-to-device copy")
-            self._check(self.lib.lt_flag_write(ctypes.c_void_p(base + self.flag_offset + 8 * d), self.count + 1,
-                                               self.flag_how, stream))
+            self._check(self.lib.lt_flag_write(ctypes.c_void_p(flags + 8 * d), self.count + 1, self.flag_how, stream))
             if side is not cur:
                 cur.wait_stream(side)
 
@@ -300,7 +307,7 @@ class _CopyWindow:
         import ctypes
         p, stream = self.count & 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for d in (1, 0):
-            self._check(self.lib.lt_flag_wait(ctypes.c_void_p(self.base + self.flag_offset + 8 * d), self.count + 1,
+            self._check(self.lib.lt_flag_wait(ctypes.c_void_p(self.flags + 8 * d), self.count + 1,
                                               ctypes.c_void_p(self._timed_out.data_ptr()), stream))
         self.count += 1
         return self._local[p][1], self._local[p][0]
@@ -319,10 +326,10 @@ class _CopyWindow:
                 with torch.cuda.device(self.device):
                     for ptr in self._opened:
                         self.lib.lt_ipc_close(ptr)
-                    if self._torch_backing is None:
-                        self.lib.lt_ipc_free(self.base)
+                    self.lib.lt_ipc_free(self.base)
+                    self.lib.lt_ipc_free(self.flags)
             finally:
-                self.base, self._opened = 0, []
+                self.base, self.flags, self._opened = 0, 0, []
 
     def __del__(self):
         try:

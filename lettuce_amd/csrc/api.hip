@@ -1674,11 +1674,16 @@ int lt_flag_wait(const uint64_t *flag, uint64_t at_least, uint32_t *timed_out, v
   return LT_OK;
 }
 // Device memory other processes of the node can map (hipIpc*): the receive windows of the copy transport
-int lt_ipc_alloc(int64_t n_bytes, void **dev_out, void *handle_out_64_bytes) {
+int lt_ipc_alloc(int64_t n_bytes, int32_t fine_grained, void **dev_out, void *handle_out_64_bytes) {
   if (!dev_out || !handle_out_64_bytes || n_bytes <= 0) return fail(LT_ERR_INVALID, "ipc alloc: null argument or %lld bytes", (long long)n_bytes);
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
   void *p = nullptr;
-  if (hipMalloc(&p, (size_t)n_bytes) != hipSuccess) return fail(LT_ERR_ALLOC, "hipMalloc of %lld bytes (ipc window) failed", (long long)n_bytes);
+  // fine_grained: memory that stays coherent with writers outside the running kernel (another device's copy engine or
+  // command processor) -- for the arrival counters a polling wave reads while it runs; the messages themselves are
+  // read by the NEXT launch and live in ordinary (cached) device memory
+  const hipError_t ea = fine_grained ? hipExtMallocWithFlags(&p, (size_t)n_bytes, hipDeviceMallocFinegrained)
+                                     : hipMalloc(&p, (size_t)n_bytes);
+  if (ea != hipSuccess) { (void)hipGetLastError(); return fail(LT_ERR_ALLOC, "allocation of %lld bytes (ipc window%s) failed", (long long)n_bytes, fine_grained ? ", fine-grained" : ""); }
   hipIpcMemHandle_t h;
   const hipError_t e = hipIpcGetMemHandle(&h, p);
   if (e != hipSuccess) { (void)hipFree(p); return fail(LT_ERR_HIP, "hipIpcGetMemHandle failed: %s", hipGetErrorString(e)); }
