@@ -105,6 +105,66 @@ def test_copy_transport_between_processes_sharing_one_gpu(tmp_path, driver, worl
     np.testing.assert_allclose(got["f1"], ref.f.numpy(), rtol=0, atol=tol * float(np.abs(ref.f.numpy()).max()))
 
 
+def _bench_loop_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import contextlib
+    import io
+    import bench
+    import lettuce_amd as lt
+    args = bench.parse(["--gpus", str(world), "--steps", "6", "--warmup", "3", "--batches", "2", "--candidate-budget", "120",
+                        "--first-candidate-budget", "120"])
+    bench.MIN_BATCH_S = 0.0
+    ctx = lt.Context("cuda:0", torch.float32, use_native=True)
+    res = [64, 16, 12 * world]
+    slab = lt.ZSlab(res)
+
+    def build(driver, transport):
+        flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 400, 0.1, lt.D3Q19(), slab=slab)
+        coll = lt.BGKCollision(flow.units.relaxation_parameter_lu)
+        if driver == "two-step":
+            return lt.TwoStepSlabSimulation(flow, coll, slab, transport=transport, direct=True)
+        return lt.SlabSimulation(flow, coll, slab, transport=transport)
+
+    wanted = [("single-step", "rccl"), ("two-step", "rccl"), ("two-step", "copy")]
+    ranks = bench.Ranks(dist, world, rank, 0, torch.device("cpu"))      # the loop's own collectives through gloo on the host
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        bench.candidate_loop(args, ranks, wanted, build, "TGV3D D3Q19 fp32 on ranks sharing one GPU", res,
+                             res[0] * res[1] * slab.nz_local, 152, "f32", probe_steps=7,
+                             cpu_baseline_row={"value": 1.0, "unit": "MLUPS", "cores": 1, "kind": "port", "sample": "stub"}
+                             if rank == 0 else None)
+    if rank == 0:
+        with open(os.path.join(out_dir, "line.json"), "w") as fh:
+            fh.write(out.getvalue())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_candidate_loop_with_the_real_kernels_on_ranks_sharing_one_gpu(tmp_path, world):
+    """bench.py's N > 1 loop as the driver will run it -- reference candidate, two-step driver over the process group,
+    two-step driver over the copy transport -- with the real kernels, 2-3 processes that share the GPU of the box, the
+    copy transport's windows mapped between the processes (HIP IPC), odd probe length: every candidate must be
+    bit-identical to the reference after the probe and after the timed batches, nothing may fail, and the line must
+    carry what the judge asks of an N > 1 line."""
+    import json
+    port = 29100 + (os.getpid() % 500) + 7 * world
+    mp.spawn(_bench_loop_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    lines = [ln for ln in open(tmp_path / "line.json").read().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    t = line["config"]["transport"]
+    assert line["n_gpus"] == world and line["value"] > 0 and t["failures"] == {}, t
+    assert set(t["warmup_ms_per_step"]) == {"single-step/rccl", "two-step/rccl", "two-step/copy"}
+    for name in ("two-step/rccl", "two-step/copy"):
+        assert "bit-identical" in t["checks"][name] and "after the timed batches too" in t["checks"][name], t["checks"]
+    assert t["ranks_seen"]["ranks"] == world and len(t["rank_checksums"]) == world
+    assert line["cpu_baseline"]["kind"] == "port" and "traffic" in line["roofline"]
+
+
 def _two_step_identity_worker(rank, port, res, steps, transport, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
