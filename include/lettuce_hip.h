@@ -39,8 +39,11 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 1
-#define LT_MAX_BOUNDARIES 7
+#define LT_ABI_VERSION 2
+/* boundaries per plan: the compiled node byte has seven index bits (the reference's uint8 no_collision_mask could
+ * name 255, lettuce/_simulation.py:63-86); plans with more than 15 keep the one-step kernels (the two-step kernels
+ * with boundaries carry the kinds as two bits per slot in one register) */
+#define LT_MAX_BOUNDARIES 127
 #define LT_MAX_Q 27
 
 enum lt_status {

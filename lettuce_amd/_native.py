@@ -23,8 +23,8 @@ from ._errors import LettuceException
 __all__ = ["NativeEngineError", "load_library", "library_path", "Plan", "STENCIL_IDS",
            "COLLISION_IDS", "BOUNDARY_KINDS"]
 
-LT_ABI_VERSION = 1
-LT_MAX_BOUNDARIES = 7
+LT_ABI_VERSION = 2
+LT_MAX_BOUNDARIES = 127
 LT_MAX_Q = 27
 
 STENCIL_IDS = {"D2Q9": 0, "D3Q19": 1, "D3Q27": 2, "D1Q3": 3, "D3Q15": 4}

@@ -509,6 +509,7 @@ int halo2(lt_plan *p, bool do_pack, void *f, int side, void *buf, void *stream) 
 // Returns the memory axis of the outlet (2 without one), or -1: not admitted.
 int masked_two_step_axis(const lt_plan *p) {
   if (!p->nsm_confined) return -1;
+  if (p->desc.n_boundaries > 15) return -1;          // two bits of kind per slot in one 32-bit register (MaskedPlanInfo)
   const int sweep = p->unit.d == 2 ? 1 : 2;          // the slowest memory axis
   if (p->unit.d < 2) return -1;
   int n_abb = 0, axis = 2;
@@ -1126,7 +1127,7 @@ int lt_plan_set_masks(lt_plan *p, const uint8_t *ncm, const uint8_t *nsm, void *
   const int sweep = p->unit.d == 2 ? 1 : 2;          // the slowest memory axis: rows in 2-D, planes in 3-D
   for (int i = 0; i < p->desc.n_boundaries; ++i) {
     const lt_boundary_desc &b = p->desc.boundaries[i];
-    if (b.kind == LT_BOUNDARY_EQUILIBRIUM) eq_slots |= 1u << (i + 1);
+    if (b.kind == LT_BOUNDARY_EQUILIBRIUM && i + 1 < 32) eq_slots |= 1u << (i + 1);   // (only read for plans the two-step kernels admit: <= 15 boundaries)
     if (b.kind != LT_BOUNDARY_ABB_OUTLET || (b.flags & LT_BOUNDARY_ABSENT)) continue;
     ++outlets;
     const int ax = mem_axis_of(p, b.axis);

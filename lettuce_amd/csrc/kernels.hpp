@@ -30,7 +30,7 @@
 namespace lt {
 
 constexpr int kThreads = 256;
-constexpr int kMaxB = 7;   // == LT_MAX_BOUNDARIES
+constexpr int kMaxB = 127;   // == LT_MAX_BOUNDARIES: what the node byte's seven index bits can name
 
 // boundary kinds (== lt_boundary_kind)
 constexpr int kBounceBack = 1, kEquilibrium = 2, kAbbOutlet = 3;

@@ -427,6 +427,50 @@ def test_random_masks_bounce_back_equilibrium_and_sparse_no_streaming(lat, res, 
     assert_close(got, sim.f.numpy(), dt, scale=4)
 
 
+@pytest.mark.parametrize("lat,res,dt,n_b,two_step", [("D3Q19", [8, 6, 10], "f64", 40, False), ("D2Q9", [16, 12], "f32", 127, False),
+                                                     ("D3Q19", [4, 8, 64], "f32", 15, True), ("D3Q19", [4, 8, 64], "f32", 16, True)])
+def test_many_boundaries_per_flow(lat, res, dt, n_b, two_step):
+    """Round 4: LT_MAX_BOUNDARIES 7 -> 127 (what the node byte's seven index bits can name; the reference's uint8 mask
+    takes 255, lettuce/_simulation.py:63-86).  n_b alternating bounce-back / equilibrium boundaries with their own
+    equilibria on random nodes, 'highest index wins', against the oracle; up to 15 boundaries the two-step kernel with
+    boundaries takes the plan (bit-identical to one-step launches), from 16 on it keeps the one-step kernel."""
+    L = orc.LATTICES[lat]
+    dtype = TORCH_DT[dt]
+    g = torch.Generator().manual_seed(23)
+    f0 = _random_state(L, res, dtype, 6)
+    e, w = orc.lattice_tensors(L, dtype)
+    units = orc.Units(10, 0.1)
+    bounds, entries = [], []
+    for i in range(n_b):
+        mask = torch.rand(res, generator=g) < 0.02
+        if i % 2 == 0:
+            bounds.append(orc.OracleBoundary("bounce_back", mask=mask))
+            entries.append({"kind": "bounce_back"})
+        else:
+            vel = torch.tensor([0.3, -0.2, 0.1][:L.d], dtype=dtype) * (1 + 0.01 * i)
+            b = orc.OracleBoundary("equilibrium_pu", mask=mask, velocity_pu=vel, pressure_pu=torch.tensor(0.001 * i, dtype=dtype))
+            bounds.append(b)
+            feq = orc.quadratic_equilibrium(units.pressure_pu_to_density_lu(b.pressure_pu), units.velocity_to_lu(vel), e, w)
+            entries.append({"kind": "equilibrium", "feq": feq.double().tolist()})
+    sim = orc.OracleSimulation(L, f0.clone(), "bgk", 0.7, units, bounds)
+    assert int(sim.no_collision_mask.max()) > min(n_b, 100) - 8               # high indices really occur
+    plan = plan_for(lat, dtype, "bgk", res, entries)
+    plan.set_masks(dev(sim.no_collision_mask), None if sim.no_streaming_mask is None else dev(sim.no_streaming_mask))
+    if two_step:
+        plan.set_two_step(1, 0)
+        admitted = plan.two_step_admitted() is None
+        assert admitted == (n_b <= 15)
+    sim.step(5)
+    got = run_engine(plan, f0.numpy(), 0.7, 5)
+    assert_close(got, sim.f.numpy(), dt, scale=4)
+    if two_step:
+        assert plan.last_run_info()["two_step_launches"] == (2 if n_b <= 15 else 0)
+        one = plan_for(lat, dtype, "bgk", res, entries)
+        one.set_masks(dev(sim.no_collision_mask), None if sim.no_streaming_mask is None else dev(sim.no_streaming_mask))
+        one.set_two_step(0)
+        np.testing.assert_array_equal(got, run_engine(one, f0.numpy(), 0.7, 5))
+
+
 @pytest.mark.parametrize("lat,res,axis,side", [("D2Q9", [10, 8], 1, -1), ("D3Q19", [8, 6, 7], 0, 1),
                                                ("D3Q27", [6, 7, 8], 2, 1), ("D1Q3", [24], 0, 1),
                                                ("D3Q15", [7, 6, 8], 1, 1)])

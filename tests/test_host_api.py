@@ -265,14 +265,14 @@ def test_library_exports_every_declared_symbol(engine_library):
     for name in declared | (set(_native.EXPERIMENT_SYMBOLS) if lib.lt_build_flags() & 1 else set()):
         assert hasattr(lib, name), name
     assert not (lib.lt_build_flags() & 1) or _native.experiments_built()
-    assert lib.lt_abi_version() == 1
+    assert lib.lt_abi_version() == 2
     # argument checks that run before any HIP call
     bad = _native._PlanDesc()
     bad.abi_version = 99
     handle = _native.ctypes.c_void_p()
     assert lib.lt_plan_create(_native.ctypes.byref(bad), _native.ctypes.byref(handle)) == 1
     assert b"ABI version" in lib.lt_last_error()
-    bad.abi_version, bad.stencil, bad.dims, bad.collision = 1, 1, 3, 2     # KBC on D3Q19
+    bad.abi_version, bad.stencil, bad.dims, bad.collision = 2, 1, 3, 2     # KBC on D3Q19
     bad.shape[0] = bad.shape[1] = bad.shape[2] = 8
     assert lib.lt_plan_create(_native.ctypes.byref(bad), _native.ctypes.byref(handle)) == 2
     assert b"KBC" in lib.lt_last_error()
@@ -298,7 +298,7 @@ def test_two_step_admission_by_descriptor_knows_the_4_gib_limit(engine_library):
 
     def limits(stencil, dtype, shape, masked, layout=0, ghosts=0):
         d = _native._PlanDesc()
-        d.abi_version, d.stencil, d.dtype, d.collision = 1, _native.STENCIL_IDS[stencil], _native.DTYPE_IDS[dtype], 1
+        d.abi_version, d.stencil, d.dtype, d.collision = _native.LT_ABI_VERSION, _native.STENCIL_IDS[stencil], _native.DTYPE_IDS[dtype], 1
         d.layout, d.ghost_planes, d.dims = layout, ghosts, len(shape)
         for a, n in enumerate(shape):
             d.shape[a] = n
@@ -317,7 +317,7 @@ def test_two_step_admission_by_descriptor_knows_the_4_gib_limit(engine_library):
     assert limits("D3Q19", torch.float32, [512, 512, 208], True, layout=1, ghosts=2) == (64, 8, True)
     assert limits("D2Q9", torch.float32, [4096, 4096], True) == (512, 1, True)
     bad = _native._PlanDesc()
-    bad.abi_version, bad.stencil, bad.dims = 1, 1, 2
+    bad.abi_version, bad.stencil, bad.dims = 2, 1, 2
     assert lib.lt_two_step_limits(c.byref(bad), 0, None, None, None) == 1 and b"3-dimensional" in lib.lt_last_error()
 
 
