@@ -440,19 +440,22 @@ def test_many_boundaries_per_flow(lat, res, dt, n_b, two_step):
     f0 = _random_state(L, res, dtype, 6)
     e, w = orc.lattice_tensors(L, dtype)
     units = orc.Units(10, 0.1)
-    bounds, entries = [], []
+    bounds = []
     for i in range(n_b):
         mask = torch.rand(res, generator=g) < 0.02
         if i % 2 == 0:
             bounds.append(orc.OracleBoundary("bounce_back", mask=mask))
-            entries.append({"kind": "bounce_back"})
         else:
             vel = torch.tensor([0.3, -0.2, 0.1][:L.d], dtype=dtype) * (1 + 0.01 * i)
-            b = orc.OracleBoundary("equilibrium_pu", mask=mask, velocity_pu=vel, pressure_pu=torch.tensor(0.001 * i, dtype=dtype))
-            bounds.append(b)
-            feq = orc.quadratic_equilibrium(units.pressure_pu_to_density_lu(b.pressure_pu), units.velocity_to_lu(vel), e, w)
-            entries.append({"kind": "equilibrium", "feq": feq.double().tolist()})
+            bounds.append(orc.OracleBoundary("equilibrium_pu", mask=mask, velocity_pu=vel, pressure_pu=torch.tensor(0.001 * i, dtype=dtype)))
     sim = orc.OracleSimulation(L, f0.clone(), "bgk", 0.7, units, bounds)
+    entries = []                                          # in the oracle's (= the reference's sorted) index order
+    for b in sim.boundaries:
+        if b.kind == "bounce_back":
+            entries.append({"kind": "bounce_back"})
+        else:
+            feq = orc.quadratic_equilibrium(units.pressure_pu_to_density_lu(b.pressure_pu), units.velocity_to_lu(b.velocity_pu), e, w)
+            entries.append({"kind": "equilibrium", "feq": feq.double().tolist()})
     assert int(sim.no_collision_mask.max()) > min(n_b, 100) - 8               # high indices really occur
     plan = plan_for(lat, dtype, "bgk", res, entries)
     plan.set_masks(dev(sim.no_collision_mask), None if sim.no_streaming_mask is None else dev(sim.no_streaming_mask))
