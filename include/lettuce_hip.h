@@ -314,6 +314,23 @@ int lt_enstrophy(lt_plan *plan, const void *f_dev, void *u_scratch_dev, double u
 int lt_mass_interior(lt_plan *plan, const void *f_dev, const uint8_t *no_mass_mask_dev, double *out_dev,
                      void *stream);
 
+/* The same two observables for one rank of the z-slab decomposition (plans with LT_LAYOUT_SLAB and
+ * ghost planes), so that a slab reporter needs no gather (observable_reporter.py:45-68, 140-158):
+ *  lt_slab_velocity   u_ext_dev [3][nz + 6][ny][nx] (nz = the rank's own planes, logical component order, lattice
+ *                     units) <- u of the plan's nz + 2 g planes, written at planes [3 - g, 3 + nz + g); the caller
+ *                     then fills planes [0, 3) and [nz + 3, nz + 6) with the neighbours' planes (6th-order
+ *                     differences reach three planes: a velocity halo exchange, host side);
+ *  lt_slab_enstrophy  *out_dev = sum over the rank's own nodes of |curl(u_scale * u)|^2, as lt_enstrophy;
+ *  lt_slab_mass_interior  *out_dev = the rank's share of lt_mass_interior: own planes only, y and the GLOBAL z index
+ *                     (z_begin + local plane, of nz_global) off their first / last value; no_mass_mask_dev is uint8 per
+ *                     node of the plan (ghost planes included, as f) or null.
+ * The caller sums the ranks' results (all-reduce). */
+int lt_slab_velocity(lt_plan *plan, const void *f_dev, void *u_ext_dev, void *stream);
+int lt_slab_enstrophy(lt_plan *plan, const void *u_ext_dev, double u_scale, double inv_dx, double *out_dev,
+                      void *stream);
+int lt_slab_mass_interior(lt_plan *plan, const void *f_dev, const uint8_t *no_mass_mask_dev, int32_t z_begin,
+                          int32_t nz_global, double *out_dev, void *stream);
+
 /* Introspection for tests and benchmarks. */
 int lt_plan_kernel_info(lt_plan *plan, int32_t *vec_width, int32_t *threads_per_block,
                         int64_t *blocks_per_launch);

@@ -86,6 +86,9 @@ SYMBOLS = {
     "lt_init_fneq": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _dbl, _vp, _vp]),
     "lt_enstrophy": (ctypes.c_int, [_vp, _vp, _vp, _dbl, _dbl, _vp, _vp]),
     "lt_mass_interior": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "lt_slab_velocity": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "lt_slab_enstrophy": (ctypes.c_int, [_vp, _vp, _dbl, _dbl, _vp, _vp]),
+    "lt_slab_mass_interior": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "lt_plan_kernel_info": (ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i32),
                                            ctypes.POINTER(_i64)]),
     "lt_plan_kernel_name": (ctypes.c_char_p, [_vp]),
@@ -631,6 +634,44 @@ class Plan:
             mask = torch.broadcast_to(no_mass_mask, self.f_shape[1:]).to(device=f.device, dtype=torch.uint8).contiguous()
         out = torch.empty((), dtype=torch.float64, device=f.device)
         self._check(self.lib.lt_mass_interior(self._handle, _ptr(f), _ptr(mask), _ptr(out), _stream_handle()))
+        if mask is not None:
+            mask.record_stream(torch.cuda.current_stream())
+        return out
+
+    # ---- a rank's share of the observables (slab plans; the slab driver exchanges / all-reduces) ----------------
+    @_on_device
+    def slab_velocity(self, f):
+        """[3, nz + 6, ny, nx] velocity field (lattice units) of this rank's planes with room for three planes of
+        either neighbour: planes [3 - g, nz + 3 + g) are written here, the outer ones by the caller."""
+        self._tensor_ok(f, self.f_shape)
+        nx, ny, nz = self.resolution
+        u = torch.empty([3, nz + 6, ny, nx], dtype=self.dtype, device=f.device)
+        self._check(self.lib.lt_slab_velocity(self._handle, _ptr(f), _ptr(u), _stream_handle()))
+        return u
+
+    @_on_device
+    def slab_enstrophy_sum(self, u_ext, u_scale: float, inv_dx: float):
+        """0-d float64 device tensor: sum over this rank's own nodes of |curl(u_scale * u)|^2"""
+        nx, ny, nz = self.resolution
+        self._tensor_ok(u_ext, [3, nz + 6, ny, nx])
+        out = torch.empty((), dtype=torch.float64, device=u_ext.device)
+        self._check(self.lib.lt_slab_enstrophy(self._handle, _ptr(u_ext), float(u_scale), float(inv_dx), _ptr(out),
+                                               _stream_handle()))
+        u_ext.record_stream(torch.cuda.current_stream())
+        return out
+
+    @_on_device
+    def slab_mass_interior(self, f, z_begin: int, nz_global: int, no_mass_mask: Optional[torch.Tensor] = None):
+        """0-d float64 device tensor: this rank's share of the Mass observable; ``no_mass_mask`` [nz + 2 g, ny, nx]"""
+        self._tensor_ok(f, self.f_shape)
+        mask = None
+        if no_mass_mask is not None:
+            if list(no_mass_mask.shape) != self.f_shape[1:]:
+                raise NativeEngineError(f"no_mass_mask shape {list(no_mass_mask.shape)}, expected {self.f_shape[1:]}")
+            mask = no_mass_mask.to(device=f.device, dtype=torch.uint8).contiguous()
+        out = torch.empty((), dtype=torch.float64, device=f.device)
+        self._check(self.lib.lt_slab_mass_interior(self._handle, _ptr(f), _ptr(mask), int(z_begin), int(nz_global),
+                                                   _ptr(out), _stream_handle()))
         if mask is not None:
             mask.record_stream(torch.cuda.current_stream())
         return out

@@ -46,7 +46,7 @@ import torch.distributed as dist
 
 from .util import LettuceException
 
-__all__ = ["ZSlab", "SlabSimulation", "TwoStepSlabSimulation", "SlabKineticEnergy"]
+__all__ = ["ZSlab", "SlabSimulation", "TwoStepSlabSimulation", "SlabKineticEnergy", "SlabEnstrophy", "SlabMass"]
 
 
 class ZSlab:
@@ -353,6 +353,31 @@ class SlabKineticEnergy:
         if self.simulation is None:
             raise LettuceException("SlabKineticEnergy is evaluated through a slab driver's reporter")
         return torch.tensor(self.simulation.kinetic_energy_pu(), dtype=torch.float64)
+
+
+class SlabEnstrophy(SlabKineticEnergy):
+    """Enstrophy of the WHOLE domain (observable_reporter.py:45-68) through a slab driver: every rank computes the
+    velocity of its planes, swaps three planes with either neighbour (the 6th-order differences reach that far),
+    reduces its own nodes on the device and the ranks' sums are all-reduced -- no gather."""
+
+    def __call__(self, f=None):
+        if self.simulation is None:
+            raise LettuceException("SlabEnstrophy is evaluated through a slab driver's reporter")
+        return torch.tensor(self.simulation.enstrophy_pu(), dtype=torch.float64)
+
+
+class SlabMass(SlabKineticEnergy):
+    """The reference's Mass observable (observable_reporter.py:140-158) of the WHOLE domain through a slab driver.
+    ``no_mass_mask``: boolean mask on the flow's extended slab (as the flow's own masks), or None."""
+
+    def __init__(self, flow, no_mass_mask=None):
+        super().__init__(flow)
+        self.mask = no_mass_mask
+
+    def __call__(self, f=None):
+        if self.simulation is None:
+            raise LettuceException("SlabMass is evaluated through a slab driver's reporter")
+        return torch.tensor(self.simulation.mass_interior(self.mask), dtype=torch.float64)
 
 
 class SlabSimulation:
@@ -746,6 +771,93 @@ class SlabSimulation:
             dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
         dx = units.convert_length_to_pu(1.0)
         return float(units.convert_incompressible_energy_to_pu(total) * dx ** 3)
+
+
+    def _all_reduced(self, total: torch.Tensor) -> torch.Tensor:
+        if self.slab.world_size > 1:
+            total = total.clone()
+            if self._host_transport and total.is_cuda:
+                host = total.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                return host
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+        return total
+
+    def _velocity_halo(self, u_ext: torch.Tensor):
+        """Fill the three outer planes per side of ``u_ext`` [3, nz_local + 6, ny, nx] with the neighbours' planes
+        (periodic ring): my first three planes go down, my last three up."""
+        nzl, s = self.nzl, self.slab
+        if nzl < 3:
+            raise LettuceException(f"enstrophy on slabs needs at least 3 planes per rank, this one has {nzl}")
+        first, last = u_ext[:, 3:6], u_ext[:, nzl:nzl + 3]
+        if s.world_size == 1:
+            u_ext[:, nzl + 3:] = first
+            u_ext[:, :3] = last
+            return
+        host = self._host_transport and u_ext.is_cuda
+        send_down, send_up = first.contiguous(), last.contiguous()
+        if host:
+            send_down, send_up = send_down.cpu(), send_up.cpu()
+        from_above, from_below = torch.empty_like(send_down), torch.empty_like(send_up)
+        ops = [dist.P2POp(dist.isend, send_down, s.prev, self.group, tag=11),
+               dist.P2POp(dist.irecv, from_above, s.next, self.group, tag=11),
+               dist.P2POp(dist.isend, send_up, s.next, self.group, tag=12),
+               dist.P2POp(dist.irecv, from_below, s.prev, self.group, tag=12)]
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        u_ext[:, nzl + 3:] = from_above.to(u_ext.device)
+        u_ext[:, :3] = from_below.to(u_ext.device)
+
+    def enstrophy_pu(self) -> float:
+        """Enstrophy of the whole domain (periodic flows, as the reference's observable)."""
+        flow, units, g, nzl = self.flow, self.flow.units, self.GHOST, self.nzl
+        f = self.f
+        dx = units.convert_length_to_pu(1.0)
+        scale = float(units.convert_velocity_to_pu(1.0))
+        if hasattr(self.engine, "slab_velocity"):
+            u_ext = self.engine.slab_velocity(f)
+        else:                                   # test stand-ins (CPU): the same field with whole-field torch ops
+            own = f[:, self.lo:self.hi].permute(0, 3, 2, 1)                     # [q, nx, ny, nzl]
+            rho = torch.sum(own, dim=0)
+            u = torch.einsum("qd,q...->d...", flow.torch_stencil.e, own) / rho  # [3, nx, ny, nzl]
+            u_ext = torch.zeros([3, nzl + 6] + list(f.shape[2:]), dtype=f.dtype, device=f.device)
+            u_ext[:, 3:nzl + 3] = u.permute(0, 3, 2, 1)
+        self._velocity_halo(u_ext)
+        if hasattr(self.engine, "slab_enstrophy_sum"):
+            total = self.engine.slab_enstrophy_sum(u_ext, scale, 1.0 / dx)
+        else:
+            from .util import torch_gradient
+            # x and y are periodic within the rank: torch_gradient's rolls are exact there; along z only the own
+            # planes [3, nzl + 3) are kept, whose differences never reach past the three neighbour planes
+            u_pu = (u_ext * scale).permute(0, 3, 2, 1)                          # [3, nx, ny, nzl + 6]
+            grad = [torch_gradient(u_pu[a], dx=dx, order=6) for a in range(3)]
+            w_z, w_x, w_y = grad[0][1] - grad[1][0], grad[2][1] - grad[1][2], grad[0][2] - grad[2][0]
+            node = w_z * w_z + (w_x * w_x + w_y * w_y)
+            total = torch.sum(node[..., 3:nzl + 3]).double()
+        total = self._all_reduced(total)
+        return float(total) * float(dx) ** 3
+
+    def mass_interior(self, no_mass_mask=None) -> float:
+        """The reference's Mass observable of the whole domain: all populations of the nodes off the first / last
+        y and GLOBAL z index, minus those of the nodes ``no_mass_mask`` (given on the extended slab) flags."""
+        s, g, nzl, h = self.slab, self.GHOST, self.nzl, self.slab.halo
+        f = self.f
+        mask = None
+        if no_mass_mask is not None:
+            mask = torch.broadcast_to(torch.as_tensor(no_mass_mask, device=f.device), self.slab.extended_resolution)
+            mask = mask[..., h - g:h + nzl + g].permute(2, 1, 0).contiguous()      # [nzl + 2g, ny, nx]
+        nz = s.global_resolution[2]
+        if hasattr(self.engine, "slab_mass_interior"):
+            total = self.engine.slab_mass_interior(f, s.z_begin, nz, mask)
+        else:
+            own = f[:, self.lo:self.hi]                                             # [q, nzl, ny, nx]
+            z = torch.arange(s.z_begin, s.z_begin + nzl, device=f.device)
+            inner = ((z > 0) & (z < nz - 1)).reshape(-1, 1, 1)
+            node = own.double().sum(dim=0)
+            total = (node[:, 1:-1] * inner).sum()
+            if mask is not None:
+                total = total - (node * mask[self.lo:self.hi].to(node.dtype)).sum()
+        return float(self._all_reduced(total))
 
 
 class TwoStepSlabSimulation(SlabSimulation):

@@ -967,23 +967,25 @@ int run(lt_plan *p, bool from_fstar, void *a, void *b, double tau, long long n, 
 }
 
 int aux(lt_plan *p, int what, const void *f, void *rho, void *u, double *out, void *stream,
-        double scale = 1.0, double inv_dx = 1.0, const unsigned char *mask = nullptr) {
+        double scale = 1.0, double inv_dx = 1.0, const unsigned char *mask = nullptr, long long u_stride = 0,
+        int z_begin = 0, int nz_global = 0) {
   if (!p) return fail(LT_ERR_INVALID, "null plan");
-  if (!f) return fail(LT_ERR_INVALID, "null population buffer");
+  if (!f && what != 8) return fail(LT_ERR_INVALID, "null population buffer");
   lt::AuxArgs a;
   memset(&a, 0, sizeof a);
   a.what = what; a.layout = p->desc.layout;
   a.f = f; a.rho = rho; a.u = u;
   a.N = p->N;
   a.stride = pop_stride_of(p);
-  if (a.stride != a.N && what != 0 && what != 2 && what != 3 && what != 4)
+  a.u_stride = u_stride; a.z_begin = z_begin; a.nz_global = nz_global;
+  if (a.stride != a.N && what != 0 && what != 2 && what != 3 && what != 4 && what != 8 && what != 9)
     return fail(LT_ERR_UNSUPPORTED, "auxiliary kernel %d reads dense population buffers only (the plan has a "
                                     "population stride of %lld)", what, a.stride);
   const long long plane = (long long)p->n0 * p->n1;
   a.first = plane * p->interior_begin;
   a.count = plane * (p->interior_end - p->interior_begin);
   a.partial = p->partial; a.reduce_blocks = kReduceBlocks; a.out = out;
-  a.n0 = p->n0; a.n1 = p->n1; a.n2 = p->n2;
+  a.n0 = p->n0; a.n1 = p->n1; a.n2 = what == 8 ? (p->interior_end - p->interior_begin) + 6 : p->n2;
   a.scale = scale; a.inv_dx = inv_dx; a.mask = mask;
   a.stream = static_cast<hipStream_t>(stream);
   const int r = p->unit.aux(a);
@@ -1059,19 +1061,20 @@ int lt_plan_create(const lt_plan_desc *d, lt_plan **out) {
   // How deep the kernels must rebuild an outlet's neighbour (neighbour_moments, DEPTH): where the planes of outlets
   // meet, an outlet's neighbour node has been rewritten by the outlets with a lower index -- and their neighbours by
   // still lower ones.  Outlets on opposite faces of one axis never meet, so the chain is as long as the number of
-  // distinct AXES the outlets lie on, minus one.  Kernels exist for depth 0 (one outlet) and 1: any list of outlets on
-  // at most two axes (every 2-D flow; the reference takes any list, lettuce/_simulation.py:57-86).
+  // distinct AXES the outlets lie on, minus one.  Kernels exist for depth 0 (one outlet), 1 (any list of outlets on at
+  // most two axes: every 2-D flow) and, in the reference layout, 2 (outlets on all three axes, whose planes meet in
+  // corners) -- the reference takes any list, lettuce/_simulation.py:57-86.
   {
     int axes = 0;
     for (int i = 0; i < d->n_boundaries; ++i)
       if (d->boundaries[i].kind == LT_BOUNDARY_ABB_OUTLET) axes |= 1 << d->boundaries[i].axis;
     const int n_axes = (axes & 1) + ((axes >> 1) & 1) + ((axes >> 2) & 1);
     p->abb_depth = n_abb <= 1 ? 0 : (n_axes <= 2 ? 1 : n_axes - 1);
-    if (p->abb_depth > 1) {
+    if (p->abb_depth > 1 && d->layout != LT_LAYOUT_REFERENCE) {
       lt_plan_destroy(p);
       return fail(LT_ERR_UNSUPPORTED, "AntiBounceBackOutlets on all three axes (their planes meet in corners, where an "
-                                      "outlet's neighbour depends on two earlier outlets) are not supported by the HIP "
-                                      "engine; outlets on one or two axes are, in any number");
+                                      "outlet's neighbour depends on two earlier outlets) exist for the reference "
+                                      "layout only; on slabs outlets on one or two axes run, in any number");
     }
   }
   const size_t bt_size = d->dtype == LT_F32 ? sizeof(lt::BoundaryTable<float>)
@@ -1250,6 +1253,40 @@ int lt_mass_interior(lt_plan *p, const void *f, const uint8_t *mask, double *out
   if (p && (p->unit.d < 2 || p->desc.layout != LT_LAYOUT_REFERENCE || p->desc.ghost_planes))
     return fail(LT_ERR_UNSUPPORTED, "interior mass: 2-D / 3-D grids in the reference layout");
   return aux(p, 6, f, nullptr, nullptr, out, s, 1.0, 1.0, mask);
+}
+
+namespace {
+int slab_plan_ok(lt_plan *p, const char *who) {
+  if (!p) return fail(LT_ERR_INVALID, "null plan");
+  if (p->desc.layout != LT_LAYOUT_SLAB || p->desc.ghost_planes < 1)
+    return fail(LT_ERR_UNSUPPORTED, "%s: for plans in the slab layout with ghost planes (a rank's share of the "
+                                    "observable); single-domain plans have lt_enstrophy / lt_mass_interior", who);
+  return LT_OK;
+}
+}  // namespace
+
+int lt_slab_velocity(lt_plan *p, const void *f, void *u_ext, void *s) {
+  if (const int rc = slab_plan_ok(p, "lt_slab_velocity")) return rc;
+  if (!u_ext) return fail(LT_ERR_INVALID, "null velocity field");
+  const long long plane = (long long)p->n0 * p->n1;
+  const long long owned = p->interior_end - p->interior_begin;
+  // node i of the plan (its ghost planes included) is node i + (3 - g) planes of the extended field
+  char *u0 = static_cast<char *>(u_ext) + (3 - p->desc.ghost_planes) * plane * p->esize;
+  return aux(p, 0, f, nullptr, u0, nullptr, s, 1.0, 1.0, nullptr, (owned + 6) * plane);
+}
+int lt_slab_enstrophy(lt_plan *p, const void *u_ext, double u_scale, double inv_dx, double *out, void *s) {
+  if (const int rc = slab_plan_ok(p, "lt_slab_enstrophy")) return rc;
+  if (!out || !u_ext) return fail(LT_ERR_INVALID, "null output / velocity field");
+  return aux(p, 8, nullptr, nullptr, const_cast<void *>(u_ext), out, s, u_scale, inv_dx);
+}
+int lt_slab_mass_interior(lt_plan *p, const void *f, const uint8_t *mask, int32_t z_begin, int32_t nz_global,
+                          double *out, void *s) {
+  if (const int rc = slab_plan_ok(p, "lt_slab_mass_interior")) return rc;
+  if (!out) return fail(LT_ERR_INVALID, "null output");
+  const int owned = p->interior_end - p->interior_begin;
+  if (z_begin < 0 || nz_global < 1 || z_begin + owned > nz_global)
+    return fail(LT_ERR_INVALID, "planes [%d, %d) of %d", z_begin, z_begin + owned, nz_global);
+  return aux(p, 9, f, nullptr, nullptr, out, s, 1.0, 1.0, mask, 0, z_begin, nz_global);
 }
 
 int lt_plan_kernel_info(lt_plan *p, int32_t *vec, int32_t *tpb, int64_t *blocks) {

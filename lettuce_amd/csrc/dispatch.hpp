@@ -43,7 +43,8 @@ struct StepArgs {
 
 struct AuxArgs {
   int what;              // 0 macroscopic, 1 equilibrium, 2 kinetic energy, 3 mass, 4 max |u|, 5 enstrophy, 6 interior mass,
-                         // 7 f_neq initialisation (scale = tau, inv_dx = the identity's cs^2)
+                         // 7 f_neq initialisation (scale = tau, inv_dx = the identity's cs^2), 8 enstrophy of a slab's
+                         // velocity field u [3][n2][n1][n0] (three neighbour planes per side), 9 interior mass of a slab
   int layout;
   const void *f;         // populations (what 0, 2, 3) / feq output (what 1; cast away const)
   void *rho;             // what 0: out, what 1: in
@@ -56,7 +57,9 @@ struct AuxArgs {
   double *out;           // device scalar
   int n0, n1, n2;        // memory extents (what 5, 6)
   double scale, inv_dx;  // what 5: u_pu = scale * u_lu, 1 / dx_pu
-  const unsigned char *mask;   // what 6: no-mass mask or null
+  const unsigned char *mask;   // what 6, 9: no-mass mask or null
+  int z_begin, nz_global;      // what 9: global index of the rank's first plane, planes of the whole grid
+  long long u_stride;          // what 0: elements between the components of u (0 = N)
   hipStream_t stream;
 };
 

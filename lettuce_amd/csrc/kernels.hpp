@@ -1533,12 +1533,13 @@ __global__ void __launch_bounds__(1024) lbm_many3d_kernel(const KParams<T> p) {
 }
 
 // ---- auxiliary kernels --------------------------------------------------------------------
-// rho [N], u [d][N] (logical axis order) from f  -- Flow.rho / Flow.u
+// rho [N], u [d][N] (logical axis order; u_stride elements between components) from f  -- Flow.rho / Flow.u
 template <typename T, class S, int LAYOUT>
 __global__ void __launch_bounds__(kThreads) macroscopic_kernel(const T *__restrict__ f,
                                                                T *__restrict__ rho_out,
                                                                T *__restrict__ u_out,
-                                                               long long N, long long stride) {
+                                                               long long N, long long stride,
+                                                               long long u_stride) {
   using M = MemMap<S, LAYOUT>;
   const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (i >= N) return;
@@ -1552,7 +1553,7 @@ __global__ void __launch_bounds__(kThreads) macroscopic_kernel(const T *__restri
   if (rho_out) rho_out[i] = rho;
   if (u_out) {
 #pragma unroll
-    for (int a = 0; a < S::D; ++a) u_out[(long long)a * N + i] = j[M::memory(a)] / rho;
+    for (int a = 0; a < S::D; ++a) u_out[(long long)a * u_stride + i] = j[M::memory(a)] / rho;
   }
 }
 
@@ -1699,15 +1700,21 @@ __global__ void __launch_bounds__(kThreads) reduce_kernel(const T *__restrict__ 
 // torch_gradient (util/utility.py:37-99) of u_pu = scale * u, the squared vorticity, fp64 partial sums.
 // d(u_c)/d(axis): sum_k w_k u_c(x - s_k e_axis), s = 3, 2, 1, -1, -2, -3, times 1 / dx -- the order of
 // the reference's expression (roll by +s reads x - s).
-template <typename T, int D>
+//
+// SLAB: u is a rank's velocity field in the slab layout, [3][n2][n1][n0] with x fastest (logical axis a on memory axis
+// a) and n2 = the rank's planes + THREE planes of the neighbours on either side; the sum runs over the planes
+// [3, n2 - 3) and nothing wraps along a2.
+template <typename T, int D, bool SLAB = false>
 __global__ void __launch_bounds__(kThreads) enstrophy_kernel(const T *__restrict__ u, int n0, int n1, int n2,
                                                             T scale, T inv_dx, double *__restrict__ partial) {
 #pragma clang fp contract(off)
   const long long N = (long long)n0 * n1 * n2;
+  const long long first = SLAB ? 3ll * n0 * n1 : 0ll, count = SLAB ? N - 2 * first : N;
   const T w[6] = {T(-1. / 60.), T(3. / 20.), T(-3. / 4.), T(3. / 4.), T(-3. / 20.), T(1. / 60.)};
   const int sh[6] = {3, 2, 1, -1, -2, -3};
   double acc = 0.0;
-  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < N; i += (long long)gridDim.x * kThreads) {
+  for (long long k = (long long)blockIdx.x * kThreads + threadIdx.x; k < count; k += (long long)gridDim.x * kThreads) {
+    const long long i = first + k;
     const int c0 = (int)(i % n0), c1 = (int)((i / n0) % n1), c2 = (int)(i / ((long long)n0 * n1));
     // derivative of component c along MEMORY axis m
     auto ddx = [&](int c, int m) -> T {
@@ -1718,14 +1725,14 @@ __global__ void __launch_bounds__(kThreads) enstrophy_kernel(const T *__restrict
         int a0 = c0, a1 = c1, a2 = c2;
         if (m == 0) { a0 = c0 - sh[k]; a0 = a0 < 0 ? a0 + n0 : (a0 >= n0 ? a0 - n0 : a0); }
         if (m == 1) { a1 = c1 - sh[k]; a1 = a1 < 0 ? a1 + n1 : (a1 >= n1 ? a1 - n1 : a1); }
-        if (m == 2) { a2 = c2 - sh[k]; a2 = a2 < 0 ? a2 + n2 : (a2 >= n2 ? a2 - n2 : a2); }
+        if (m == 2) { a2 = c2 - sh[k]; if (!SLAB) a2 = a2 < 0 ? a2 + n2 : (a2 >= n2 ? a2 - n2 : a2); }
         const T v = w[k] * (uc[((long long)a2 * n1 + a1) * n0 + a0] * scale);
         r = k == 0 ? v : r + v;
       }
       return r * inv_dx;
     };
-    // logical axis a lives on memory axis D - 1 - a (reference layout)
-    auto grad = [&](int c, int a) -> T { return ddx(c, D - 1 - a); };
+    // logical axis a lives on memory axis D - 1 - a (reference layout) / a (slab layout)
+    auto grad = [&](int c, int a) -> T { return ddx(c, SLAB ? a : D - 1 - a); };
     const T wz = grad(0, 1) - grad(1, 0);
     T node = wz * wz;
     if constexpr (D == 3) {
@@ -1753,6 +1760,31 @@ __global__ void __launch_bounds__(kThreads) interior_mass_kernel(const T *__rest
     double node = 0.0;
 #pragma unroll
     for (int q = 0; q < Q; ++q) node += (double)f[(long long)q * N + i];
+    acc += (inner ? node : 0.0) - (masked ? node : 0.0);
+  }
+  const double s = block_sum<false>(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// The same over a rank's slab (slab layout, `stride` elements between populations): nodes [first, first + count) are
+// the rank's own planes, plane `first / (n0 n1)` is plane z_begin of the nz_global planes of the whole grid; the
+// reference's two fastest axes are y and z, i.e. a1 and the GLOBAL a2 here.  `mask` is indexed like the nodes of f.
+template <typename T, int Q>
+__global__ void __launch_bounds__(kThreads) interior_mass_slab_kernel(const T *__restrict__ f, long long stride,
+                                                                     long long first, long long count, int n0, int n1,
+                                                                     int z_begin, int nz_global,
+                                                                     const unsigned char *__restrict__ mask,
+                                                                     double *__restrict__ partial) {
+  double acc = 0.0;
+  for (long long k = (long long)blockIdx.x * kThreads + threadIdx.x; k < count; k += (long long)gridDim.x * kThreads) {
+    const long long i = first + k;
+    const int c1 = (int)((i / n0) % n1), z = z_begin + (int)(k / ((long long)n0 * n1));
+    const bool inner = c1 > 0 && c1 < n1 - 1 && z > 0 && z < nz_global - 1;
+    const bool masked = mask != nullptr && mask[i] != 0;
+    if (!inner && !masked) continue;
+    double node = 0.0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) node += (double)f[(long long)q * stride + i];
     acc += (inner ? node : 0.0) - (masked ? node : 0.0);
   }
   const double s = block_sum<false>(acc);

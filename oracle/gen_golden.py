@@ -443,6 +443,13 @@ if __name__ == "__main__":
     two_outlets_case("three_outlets_d3q19_bgk_f32", [8, 7, 6], lt.D3Q19(), "f32", outlets=[[1, 0, 0], [0, 0, 1], [0, 0, -1]])
     two_outlets_case("four_outlets_d3q27_bgk_f64", [6, 8, 7], lt.D3Q27(), "f64",
                      outlets=[[0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]])
+    # round 4: outlets on all THREE axes (their planes meet in corners: an outlet's neighbour depends on two earlier ones)
+    two_outlets_case("outlets_on_three_axes_d3q19_bgk_f64", [8, 7, 6], lt.D3Q19(), "f64",
+                     outlets=[[1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    two_outlets_case("outlets_on_three_axes_d3q27_bgk_f32", [7, 8, 6], lt.D3Q27(), "f32",
+                     outlets=[[1, 0, 0], [0, -1, 0], [0, 1, 0], [0, 0, 1], [0, 0, -1]])
+    two_outlets_case("outlets_on_three_axes_d3q15_bgk_f64", [6, 7, 8], lt.D3Q15(), "f64",
+                     outlets=[[0, 0, -1], [0, 1, 0], [1, 0, 0], [0, -1, 0]])
     if wanted("native") or wanted("hand"):
         hand_set_cases()
     if wanted("operators"):

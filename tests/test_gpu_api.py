@@ -410,6 +410,45 @@ def test_flow_with_two_outlets_native_equals_the_reference_path():
         np.testing.assert_allclose(got.f.cpu().numpy(), want.f.numpy(), rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("order", ["xyz", "zyx", "yzx"])
+def test_flow_with_outlets_on_all_three_axes_native_equals_the_reference_path(order):
+    """lt.Simulation on a native context with AntiBounceBackOutlets on +x, +y and +z (planes meeting in a corner, where an
+    outlet's neighbour was rewritten by two earlier outlets; lettuce/_simulation.py:57-86 takes any list) == the
+    non-native (reference) path of the mirror on the CPU, for three orders of the outlets."""
+    res = [9, 8, 7]
+
+    def build(c):
+        def named(axis):
+            class Out(lt.AntiBounceBackOutlet):
+                def __str__(self):
+                    return f"outlet-{order.index('xyz'[axis])}"
+            return Out
+
+        class ThreeOutlets(lt.TaylorGreenVortex):
+            made = None
+
+            @property
+            def boundaries(self):
+                if self.made is None:
+                    x = self.grid[0]
+                    block = torch.zeros(res, dtype=torch.bool, device=self.context.device)
+                    block[4:6, 3:5, 2:4] = True
+                    outs = [named(a)([1 if k == a else 0 for k in range(3)], self) for a in range(3)]
+                    self.made = ([lt.EquilibriumBoundaryPU(self.context, torch.abs(x) < 1e-6, [0.3, 0.0, 0.0])] + outs
+                                 + [lt.BounceBackBoundary(block)])
+                return self.made
+        return ThreeOutlets(c, res, 100, 0.05, lt.D3Q27())
+    want = build(lt.Context("cpu", torch.float64, use_native=False))
+    got = build(gpu("f64"))
+    sw = lt.Simulation(want, lt.KBCCollision(), [])
+    sg = lt.Simulation(got, lt.KBCCollision(), [])
+    for sim_ in (sw, sg):
+        assert [str(b) for b in sim_.boundaries[1:] if str(b).startswith("outlet")] == ["outlet-0", "outlet-1", "outlet-2"]
+    sw(5); sg(5)
+    assert sg._native.plan.kernel_name().endswith(", 2>")           # the three-axes instantiation ran
+    np.testing.assert_allclose(got.f.cpu().numpy(), want.f.numpy(), rtol=0, atol=1e-12)
+
+
 def test_cfg1_simplest_tgv_energy_anchors():
     """BASELINE configs[0] = examples/00_simplest_TGV.py (D2Q9 128^2 fp64 Re 100 Ma 0.05, BGK,
     1000 steps) on the HIP engine against the reference CPU path: populations after 100 steps

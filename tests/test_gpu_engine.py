@@ -860,7 +860,11 @@ TWO_OUTLETS = [("two_outlets_d2q9_bgk_f64", "D2Q9", "f64"), ("two_outlets_d3q19_
                ("two_outlets_d3q19_bgk_f32", "D3Q19", "f32"),
                # round 3: any number of outlets on at most two axes (+x, +y, -y; +x, +z, -z; +-y, +-z)
                ("three_outlets_d2q9_bgk_f64", "D2Q9", "f64"), ("three_outlets_d3q19_bgk_f32", "D3Q19", "f32"),
-               ("four_outlets_d3q27_bgk_f64", "D3Q27", "f64")]
+               ("four_outlets_d3q27_bgk_f64", "D3Q27", "f64"),
+               # round 4: outlets on all three axes (+x +y +z; +x -y +y +z -z; -z +y +x -y), planes meeting in corners
+               ("outlets_on_three_axes_d3q19_bgk_f64", "D3Q19", "f64"),
+               ("outlets_on_three_axes_d3q27_bgk_f32", "D3Q27", "f32"),
+               ("outlets_on_three_axes_d3q15_bgk_f64", "D3Q15", "f64")]
 
 
 @pytest.mark.parametrize("name,lat,dt", TWO_OUTLETS, ids=[t[0] for t in TWO_OUTLETS])
@@ -868,7 +872,8 @@ def test_two_anti_bounce_back_outlets_against_the_reference(name, lat, dt):
     """Plans with several outlets whose planes meet in edges (VERDICT r01 item 8, r02 "missing" 5; reference: any list
     of boundaries, lettuce/_simulation.py:57-86, anti_bounce_back_outlet.py:22-103): on such an edge an outlet's
     neighbour has already been rewritten by the outlets with a lower index, so its state is rebuilt in full
-    (neighbour_moments, DEPTH 1) -- enough for any number of outlets on at most two axes."""
+    (neighbour_moments, DEPTH 1) -- enough for any number of outlets on at most two axes; with outlets on all three
+    axes the planes meet in corners and the chain is one longer (DEPTH 2, reference layout; round 4)."""
     g = golden(name)
     L = orc.LATTICES[lat]
     dtype = TORCH_DT[dt]
@@ -887,16 +892,16 @@ def test_two_anti_bounce_back_outlets_against_the_reference(name, lat, dt):
             entries.append({"kind": "equilibrium", "feq": feq_in.double().tolist()})
     plan = plan_for(lat, dtype, "bgk", g["f0"].shape[1:], entries)
     plan.set_masks(dev(g["no_collision_mask"]), dev(unpack_nsm(g)))
-    assert plan.kernel_name().endswith(", 1>")               # the two-outlet instantiation
+    axes = {e["axis"] for e in entries if e["kind"] == "abb_outlet"}
+    assert plan.kernel_name().endswith(f", {len(axes) - 1}>")       # the instantiation for that depth
     for n in (1, 2, 6):
         got = run_engine(plan, g["f0"], float(g["tau"]), n)
         assert_close(got, g[f"f{n}"], dt, scale=10 if dt == "f64" else 1)
-    if L.d == 3:
-        # outlets on all three axes meet in corners (a chain of two earlier outlets): refused, with the reason
-        third = [a for a in range(3) if a not in {e["axis"] for e in entries if e["kind"] == "abb_outlet"}]
-        if third:
-            with pytest.raises(Exception, match="all three axes"):
-                plan_for(lat, dtype, "bgk", g["f0"].shape[1:], entries + [{"kind": "abb_outlet", "axis": third[0], "side": -1}])
+    if L.d == 3 and len(axes) == 3:
+        # on slabs outlets on all three axes are refused, with the reason
+        from lettuce_amd._native import Plan, LAYOUT_SLAB
+        with pytest.raises(Exception, match="all three axes"):
+            Plan(lat, dtype, "bgk", [int(r) for r in g["resolution"]], entries, layout=LAYOUT_SLAB, ghost_planes=1)
 
 
 BIT_IDENTICAL = [t for t in TGV if t[2] == "bgk"]
@@ -1673,3 +1678,37 @@ def test_masked_two_step_on_resident_populations_equals_the_dense_path(name, lat
         plan.resident_store(out)
         np.testing.assert_array_equal(out.cpu().numpy(), dense)
         assert_close(dense, g[f"f{n}"], dt)
+
+
+@pytest.mark.parametrize("driver,dt,res", [("SlabSimulation", "f64", [20, 12, 10]), ("TwoStepSlabSimulation", "f32", [64, 8, 12]),
+                                           ("TwoStepSlabSimulation", "f64", [32, 16, 8])])
+def test_enstrophy_and_mass_of_a_slab_on_the_device(driver, dt, res):
+    """lt_slab_velocity / lt_slab_enstrophy / lt_slab_mass_interior (one rank: its own neighbour) against the oracle's
+    Enstrophy and Mass observables (observable_reporter.py:45-68, 140-158) on the same populations -- one and two
+    ghost planes, dense and padded populations; fp64 partial sums against torch's pairwise fp32 sums in the tolerance."""
+    import lettuce_amd as lt
+    dtype = TORCH_DT[dt]
+    ctx = lt.Context("cuda:0", dtype, use_native=True)
+    slab = lt.ZSlab(res, 0, 1)
+    flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 400, 0.1, lt.D3Q19(), slab=slab)
+    sim = getattr(lt, driver)(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab)
+    mask = torch.zeros(res, dtype=torch.bool)
+    mask[1:5, 0:3, res[2] - 2:] = True                      # touches the last global z plane and the y border
+    mask_ext = mask[:, :, slab.z_indices()]
+    ref = orc.taylor_green(res, 400, 0.1, "D3Q19", dtype)
+    tol = 1e-11 if dt == "f64" else 2e-5
+    for n in (0, 3):
+        if n:
+            sim(n); ref.step(n)
+        f = sim.gather_f().cpu()
+        want_e = float(orc.enstrophy_pu(f.double(), ref.lat, ref.units))
+        want_m = float(orc.mass_observable(f.double(), mask))
+        want_p = float(orc.mass_observable(f.double(), None))
+        assert sim.enstrophy_pu() == pytest.approx(want_e, rel=tol)
+        assert sim.mass_interior(mask_ext) == pytest.approx(want_m, rel=1e-12 if dt == "f64" else 1e-7)
+        assert sim.mass_interior(None) == pytest.approx(want_p, rel=1e-12 if dt == "f64" else 1e-7)
+    # what the entry points refuse: a single-domain plan
+    from lettuce_amd._native import Plan, NativeEngineError
+    dense = Plan("D3Q19", dtype, "bgk", res, [])
+    with pytest.raises(NativeEngineError, match="slab layout"):
+        dense._check(dense.lib.lt_slab_enstrophy(dense._handle, None, 1.0, 1.0, None, None))

@@ -38,8 +38,9 @@ def _worker(rank, world, port, res, steps, dtype_name, overlap, out_dir, driver=
         assert sim._signalled_ok() and not sim.engine.wait_timed_out()
     f1 = sim.gather_f()
     ke = sim.kinetic_energy_pu()
+    ens, mass = sim.enstrophy_pu(), sim.mass_interior(None)
     if rank == 0:
-        np.savez(os.path.join(out_dir, "out.npz"), f1=f1.cpu().numpy(), ke=ke)
+        np.savez(os.path.join(out_dir, "out.npz"), f1=f1.cpu().numpy(), ke=ke, ens=ens, mass=mass)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,6 +58,9 @@ def test_ranks_sharing_one_gpu(tmp_path, world, overlap):
     ref.step(steps)
     np.testing.assert_allclose(got["f1"], ref.f.numpy(), rtol=0, atol=1e-13)
     assert float(got["ke"]) == pytest.approx(float(orc.kinetic_energy_pu(ref.f, ref.lat, ref.units)), rel=1e-11)
+    # the slab observables: velocity planes swapped between the ranks (staged through the host for gloo), device sums
+    assert float(got["ens"]) == pytest.approx(float(orc.enstrophy_pu(ref.f, ref.lat, ref.units)), rel=1e-11)
+    assert float(got["mass"]) == pytest.approx(float(orc.mass_observable(ref.f, None)), rel=1e-12)
 
 
 @pytest.mark.parametrize("world,overlap,steps,dtype_name,signalled",

@@ -212,7 +212,11 @@ TWO_OUTLETS = [("two_outlets_d2q9_bgk_f64", "D2Q9", "f64"), ("two_outlets_d3q19_
                ("two_outlets_d3q19_bgk_f32", "D3Q19", "f32"),
                # round 3: any number of outlets on at most two axes (+x, +y, -y; +x, +z, -z; +-y, +-z)
                ("three_outlets_d2q9_bgk_f64", "D2Q9", "f64"), ("three_outlets_d3q19_bgk_f32", "D3Q19", "f32"),
-               ("four_outlets_d3q27_bgk_f64", "D3Q27", "f64")]
+               ("four_outlets_d3q27_bgk_f64", "D3Q27", "f64"),
+               # round 4: outlets on all three axes (+x +y +z; +x -y +y +z -z; -z +y +x -y), planes meeting in corners
+               ("outlets_on_three_axes_d3q19_bgk_f64", "D3Q19", "f64"),
+               ("outlets_on_three_axes_d3q27_bgk_f32", "D3Q27", "f32"),
+               ("outlets_on_three_axes_d3q15_bgk_f64", "D3Q15", "f64")]
 
 
 def two_outlets_boundaries(g, dtype):

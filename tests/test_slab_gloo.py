@@ -375,3 +375,62 @@ def test_slab_ranks_with_an_outlet_along_the_decomposed_axis(tmp_path, world):
     flow = _z_channel(lt, ctx, res)
     lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])(steps)
     np.testing.assert_allclose(got["f1"], flow.f.numpy(), rtol=0, atol=1e-13)
+
+
+def _observables_worker(rank, world, port, res, steps, driver, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import io
+    import contextlib
+    import lettuce_amd as lt
+    from slab_cpu_engine import OracleSlabEngine
+    ctx = lt.Context("cpu", torch.float64, use_native=False)
+    slab = lt.ZSlab(res)
+    flow = lt.TaylorGreenVortex(ctx, slab.extended_resolution, 400, 0.1, lt.D3Q19(), slab=slab)
+    # a no-mass mask given like the flow's own masks: on the extended slab (here: a block that crosses the cut)
+    mask = torch.zeros(res, dtype=torch.bool)
+    mask[1:4, 2:5, res[2] // 2 - 2:res[2] // 2 + 1] = True
+    mask = mask[:, :, slab.z_indices()]
+    ens, mass = [], []
+    with contextlib.redirect_stdout(io.StringIO()):
+        reps = [lt.ObservableReporter(lt.SlabEnstrophy(flow), interval=2, out=ens),
+                lt.ObservableReporter(lt.SlabMass(flow, no_mass_mask=mask), interval=2, out=mass)]
+    sim = getattr(lt, driver)(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), slab, reporter=reps,
+                              engine=OracleSlabEngine("D3Q19", torch.float64, "bgk"))
+    sim(steps)
+    plain = sim.mass_interior(None)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "out.npz"), ens=np.array(ens), mass=np.array(mass), plain=plain)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,driver", [(2, "SlabSimulation"), (3, "SlabSimulation"), (2, "TwoStepSlabSimulation")])
+def test_enstrophy_and_mass_observables_on_slabs_need_no_gather(tmp_path, world, driver):
+    """SlabEnstrophy / SlabMass (observable_reporter.py:45-68, 140-158) through the slab driver: the ranks swap three
+    planes of the velocity field (6th-order differences), reduce their own nodes and all-reduce; the series equals
+    the single-domain oracle's.  The mask crosses the cut, the first / last GLOBAL z plane is excluded once."""
+    from oracle import lettuce_oracle as orc
+    res, steps = [8, 6, 12], 4
+    port = 29500 + (os.getpid() % 2000) + world + (20 if driver != "SlabSimulation" else 0)
+    mp.spawn(_observables_worker, args=(world, port, res, steps, driver, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "out.npz")
+    ref = orc.taylor_green(res, 400, 0.1, "D3Q19", torch.float64)
+    mask = torch.zeros(res, dtype=torch.bool)
+    mask[1:4, 2:5, res[2] // 2 - 2:res[2] // 2 + 1] = True
+    want_e, want_m = {}, {}
+    for i in range(steps + 1):
+        if i % 2 == 0:
+            want_e[i] = float(orc.enstrophy_pu(ref.f, ref.lat, ref.units))
+            want_m[i] = float(orc.mass_observable(ref.f, mask))
+        ref.step(1)
+    ref = orc.taylor_green(res, 400, 0.1, "D3Q19", torch.float64)
+    ref.step(steps)
+    assert [int(r[0]) for r in got["ens"]] == sorted(want_e) == [int(r[0]) for r in got["mass"]]
+    for row in got["ens"]:
+        assert row[2] == pytest.approx(want_e[int(row[0])], rel=1e-11)
+    for row in got["mass"]:
+        assert row[2] == pytest.approx(want_m[int(row[0])], rel=1e-12)
+    assert float(got["plain"]) == pytest.approx(float(orc.mass_observable(ref.f, None)), rel=1e-12)
