@@ -1237,6 +1237,76 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
 
   // intermediate planes s-1 .. s+seg_len are needed (relative indices 0 .. seg_len+1)
   const int last = s + seg_len < range_end ? s + seg_len : range_end;
+  if constexpr (PACK && NPT == 1 && NPB == 1) {
+    if (last - s == 2) {
+      // Slab edge launch: two output planes per workgroup, i.e. four intermediate planes and no sweep to amortise a
+      // serial prologue over, with all 256 workgroups of a round in lock-step (memory idle while they collide, compute
+      // units idle while they load).  Straight-line schedule on two register sets with the loads of plane j + 1 in
+      // flight behind the collide of plane j -- what the steady state of the sweep does.  Every thread loads (the 44
+      // of 704 without an intermediate node read the plane's first node): a load under `if (in_a)` leaves the other
+      // lanes' registers undefined, the compiler zeroes them AFTER the loads and that write waits for the loads.
+      if (!in_a) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) voff[0][a][c] = 0u;
+      }
+      auto load_into = [&](int plane, T (&dst)[S::Q][1]) {
+        const int g2 = plane, g2m = plane - 1, g2p = plane + 1;      // slab layout: no wrap along a2
+        static_for<S::Q>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          constexpr int e0 = M::e(q, 0), e1 = M::e(q, 1), e2 = M::e(q, 2), rank = crossing_rank<S, LAYOUT, q>();
+          const int z = e2 == 0 ? g2 : (e2 > 0 ? g2m : g2p);
+          const T *base = p.in + ((long long)q * p.Ni + (long long)((unsigned)z * plane_nodes));
+          if constexpr (e2 >= 0) {
+            if (p.ghost_lo != nullptr && z < p.lo)
+              base = p.ghost_lo + (size_t)(e2 == 0 ? rank : (z == p.lo - 1 ? NC + rank : NC + NU + rank)) * plane_nodes;
+          }
+          if constexpr (e2 <= 0) {
+            if (p.ghost_hi != nullptr && z >= p.hi)
+              base = p.ghost_hi + (size_t)(e2 == 0 ? rank : (z == p.hi ? NC + rank : NC + ND + rank)) * plane_nodes;
+          }
+          dst[q][0] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + voff[0][e1 + 1][e0 + 1]);
+        });
+      };
+      auto collide_into_lds = [&](T (&src)[S::Q][1], int r, int r3) {
+        if constexpr (COLL == 1) collide_bgk<T, S, LAYOUT, 1, 0>(src, p.tau_inv);
+        if constexpr (COLL == 3) collide_bgk_fast<T, S, LAYOUT, 1, 0>(src, p.tau_inv);
+        if (in_a) {
+          static_for<S::Q>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int e2 = M::e(q, 2), rank = crossing_rank<S, LAYOUT, q>();
+            if constexpr (e2 > 0) lds_u[r & 3][rank][a_at[0]] = src[q][0];
+            else if constexpr (e2 == 0) lds_c[r3][rank][a_at[0]] = src[q][0];
+            else lds_d[r & 1][rank][a_at[0]] = src[q][0];
+          });
+        }
+      };
+      // (sched_barrier: the register-minimising scheduler of this unit sinks the loads behind the collide otherwise)
+      T pre2[S::Q][1];
+      load_into(s - 1, pre); load_into(s, pre2);
+      __builtin_amdgcn_sched_barrier(0);
+      collide_into_lds(pre, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_into(s + 1, pre);
+      __builtin_amdgcn_sched_barrier(0);
+      collide_into_lds(pre2, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_into(s + 2, pre2);
+      __builtin_amdgcn_sched_barrier(0);
+      collide_into_lds(pre, 2, 2);
+      lds_barrier();
+      read_b(1, 1);
+      collide_into_lds(pre2, 3, 0);
+      collide_b();
+      store_b(s, std::integral_constant<int, 1>{});
+      lds_barrier();
+      read_b(2, 2);
+      collide_b();
+      store_b(s + 1, std::integral_constant<int, 1>{});
+      return;
+    }
+  }
   load_a(s - 1); compute_a(0, 0);
   load_a(s);     compute_a(1, 1);
   load_a(s + 1); compute_a(2, 2);
