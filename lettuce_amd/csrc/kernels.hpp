@@ -1269,35 +1269,44 @@ lbm2_kernel(const KParams<T> p, const int seg_len) {
           dst[q][0] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + voff[0][e1 + 1][e0 + 1]);
         });
       };
-      auto collide_into_lds = [&](T (&src)[S::Q][1], int r, int r3) {
+      // KEEP: which populations of the plane anybody reads -- bit 0: those moving up (the output plane above pulls
+      // them), bit 1: in-plane, bit 2: moving down.  The first intermediate plane only feeds the output plane above
+      // it, the last one only the plane below: 38 of the 76 post-collision populations of the four planes are needed,
+      // the others are neither stored nor (dead code to the compiler) computed.
+      auto collide_into_lds = [&](T (&src)[S::Q][1], int r, int r3, auto keep) {
+        constexpr int KEEP = decltype(keep)::value;
         if constexpr (COLL == 1) collide_bgk<T, S, LAYOUT, 1, 0>(src, p.tau_inv);
         if constexpr (COLL == 3) collide_bgk_fast<T, S, LAYOUT, 1, 0>(src, p.tau_inv);
         if (in_a) {
           static_for<S::Q>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             constexpr int e2 = M::e(q, 2), rank = crossing_rank<S, LAYOUT, q>();
-            if constexpr (e2 > 0) lds_u[r & 3][rank][a_at[0]] = src[q][0];
-            else if constexpr (e2 == 0) lds_c[r3][rank][a_at[0]] = src[q][0];
-            else lds_d[r & 1][rank][a_at[0]] = src[q][0];
+            if constexpr (e2 > 0) { if constexpr (KEEP & 1) lds_u[r & 3][rank][a_at[0]] = src[q][0]; }
+            else if constexpr (e2 == 0) { if constexpr (KEEP & 2) lds_c[r3][rank][a_at[0]] = src[q][0]; }
+            else { if constexpr (KEEP & 4) lds_d[r & 1][rank][a_at[0]] = src[q][0]; }
           });
         }
       };
+      using Up = std::integral_constant<int, 1>;
+      using UpIn = std::integral_constant<int, 3>;
+      using InDown = std::integral_constant<int, 6>;
+      using Down = std::integral_constant<int, 4>;
       // (sched_barrier: the register-minimising scheduler of this unit sinks the loads behind the collide otherwise)
       T pre2[S::Q][1];
       load_into(s - 1, pre); load_into(s, pre2);
       __builtin_amdgcn_sched_barrier(0);
-      collide_into_lds(pre, 0, 0);
+      collide_into_lds(pre, 0, 0, Up{});
       __builtin_amdgcn_sched_barrier(0);
       load_into(s + 1, pre);
       __builtin_amdgcn_sched_barrier(0);
-      collide_into_lds(pre2, 1, 1);
+      collide_into_lds(pre2, 1, 1, UpIn{});
       __builtin_amdgcn_sched_barrier(0);
       load_into(s + 2, pre2);
       __builtin_amdgcn_sched_barrier(0);
-      collide_into_lds(pre, 2, 2);
+      collide_into_lds(pre, 2, 2, InDown{});
       lds_barrier();
       read_b(1, 1);
-      collide_into_lds(pre2, 3, 0);
+      collide_into_lds(pre2, 3, 0, Down{});
       collide_b();
       store_b(s, std::integral_constant<int, 1>{});
       lds_barrier();
