@@ -733,11 +733,13 @@ def slab_bench(args, lt, dist, world, rank, local_rank, device):
             # "rccl-edges": edge launches + pack / unpack beside the interior launch (rounds 1-2)
             # "rccl-signalled": one launch per double step whose edge workgroups run first and release the exchange
             # "window-fused": edge launches store into the neighbour's window themselves, one stream
+            # "copy-2streams": the copy transport with a stream of its own per direction (two copy engines side by side)
             return lt.TwoStepSlabSimulation(flow, coll, slab, overlap=not args.no_overlap,
                                             transport=transport.split("-")[0],
                                             fused_remote_pack=transport.endswith("-fused"),
                                             signalled=transport.endswith("-signalled"),
-                                            direct=transport in ("rccl", "copy"))
+                                            direct=transport in ("rccl", "copy", "copy-2streams"),
+                                            copy_streams=2 if transport == "copy-2streams" else None)
         return lt.SlabSimulation(flow, coll, slab, overlap=not args.no_overlap, transport=transport)
 
     # Candidates: slab driver (two lattice updates per launch and one halo exchange per two updates / one update per
@@ -752,6 +754,13 @@ def slab_bench(args, lt, dist, world, rank, local_rank, device):
         # bit-identical to single-step/rccl twice and faster than the held line; a message that does not arrive ends in
         # a time-out the driver raises after the batch (nothing traps), i.e. in config.transport.failures
         wanted.insert(wanted.index(("two-step", "rccl")) + 1, ("two-step", "copy"))
+        if world > 1:
+            # across real links the two messages of an exchange travel one after the other when they share a stream
+            # (an SDMA engine moves ~50 GB/s: 2 x 0.4 ms against a 0.5 ms sweep); with a stream per direction two
+            # engines work side by side.  On ONE device the extra streams cost the sweep (profiles/
+            # r04g_slab_stream_count.jsonl), so the rehearsal does not offer it.  Never measured across real links: a
+            # candidate like the others, kept only if it is bit-identical twice and faster.
+            wanted.insert(wanted.index(("two-step", "copy")) + 1, ("two-step", "copy-2streams"))
     if args.transport == "all" and "two-step" in drivers and not args.no_overlap:
         at = wanted.index(("two-step", "rccl")) + 1
         wanted[at:at] = [("two-step", "rccl-edges"), ("two-step", "rccl-signalled")]
@@ -805,14 +814,17 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
     window_ok = None
 
     def describe(driver, transport):
+        how_copy = ("halo messages moved by device-to-device copies without compute units (copy engines) into receive "
+                    "windows the neighbours mapped through HIP IPC, arrival counters written in stream order")
         how = {"rccl": "RCCL send/recv of the halo messages",
                "rccl-edges": "RCCL send/recv ghost planes; edge launches, pack and unpack beside the interior launch",
                "rccl-signalled": "RCCL send/recv ghost planes, released by the edge workgroups of the one launch per double step",
-               "copy": "halo messages moved by device-to-device copies without compute units (copy engines) into receive "
-                       "windows the neighbours mapped through HIP IPC, arrival counters written in stream order",
+               "copy": how_copy, "copy-2streams": how_copy,
                }.get(transport, "one-sided ghost-plane stores into peer windows (xGMI peer access)"
                      + (", issued by the edge launches" if transport.endswith("-fused") else ""))
-        if driver == "two-step" and transport in ("rccl", "copy"):
+        if transport == "copy-2streams":
+            how = how_copy + ", one stream per direction"
+        if driver == "two-step" and transport in ("rccl", "copy", "copy-2streams"):
             how += (" straight out of / into the buffers the edge launch writes / reads (no pack, no unpack); edge launch, "
                     "then the planes in between, on one stream")
         how += ("; two lattice updates per launch, one exchange per two updates" if driver == "two-step"
@@ -986,6 +998,7 @@ def candidate_loop(args, ranks, wanted, build, what, global_res, nodes_per_rank,
             line["config"]["transport"]["rank_checksums"] = sums
             if getattr(cand, "_cw", None) is not None:
                 line["config"]["transport"]["copy_engine"] = sorted(cand._cw.engines_used)
+                line["config"]["transport"]["copy_streams"] = cand._cw.n_streams
             if held.line is None or line["value"] > held.line["value"]:
                 held.line = line
             else:

@@ -211,7 +211,8 @@ class _CopyWindow:
     scatter of 4 % between batches -- an SDMA engine moves a 20 MB message within one device at ~57 GB/s (0.35 ms),
     two of them beside a sweep that saturates HBM disturb it more than RCCL's kernel does."""
 
-    def __init__(self, shape, dtype, device, slab: ZSlab, group, engine: int = 0, flag_how: int = 1):
+    def __init__(self, shape, dtype, device, slab: ZSlab, group, engine: int = 0, flag_how: int = 1,
+                 streams: Optional[int] = None):
         import ctypes
         from ._native import load_library
         self.lib = load_library()
@@ -268,8 +269,11 @@ class _CopyWindow:
         # of 0.30 ms per step whenever RCCL's streams existed in the process too (tools/slab_order_probe.py,
         # profiles/r04g_slab_stream_count.jsonl; GPU_MAX_HW_QUEUES = 8 / 16 changed nothing, 2 gave 0.295).
         # LT_SLAB_COPY_STREAMS=2 to A/B on real links.
-        two = os.environ.get("LT_SLAB_COPY_STREAMS", "1") == "2"
+        # ``streams=2`` (the driver's ``copy_streams``) is the same choice per simulation: bench.py --gpus N offers
+        # both as candidates, because across real links two messages through ONE stream travel one after the other.
+        two = (int(streams) == 2) if streams is not None else os.environ.get("LT_SLAB_COPY_STREAMS", "1") == "2"
         self._streams = _copy_streams(self.device, 2 if two else 1)
+        self.n_streams = 2 if two else 1
 
     def _check(self, code):
         if code != 0:
@@ -401,7 +405,8 @@ class SlabSimulation:
     POPULATION_PAD = 0
 
     def __init__(self, flow, collision, slab: ZSlab, reporter=None, engine=None, group=None,
-                 overlap: bool = True, comm_priority: int = -1, transport: str = "rccl"):
+                 overlap: bool = True, comm_priority: int = -1, transport: str = "rccl",
+                 copy_streams: Optional[int] = None):
         if list(flow.resolution) != slab.extended_resolution:
             raise LettuceException(f"flow resolution {flow.resolution} != extended slab "
                                    f"{slab.extended_resolution}")
@@ -502,7 +507,7 @@ class SlabSimulation:
                                        "with more than one rank)")
             self._cw = _CopyWindow(shape, self.f.dtype, self.f.device, slab, group,
                                    engine=int(os.environ.get("LT_SLAB_COPY_ENGINE", "0")),
-                                   flag_how=int(os.environ.get("LT_SLAB_FLAG_HOW", "1")))
+                                   flag_how=int(os.environ.get("LT_SLAB_FLAG_HOW", "1")), streams=copy_streams)
         if transport == "window":
             if self.context.device.type != "cuda" or not (dist.is_available() and dist.is_initialized()):
                 raise LettuceException("the window transport needs device memory and an initialised "
