@@ -1712,3 +1712,66 @@ def test_enstrophy_and_mass_of_a_slab_on_the_device(driver, dt, res):
     dense = Plan("D3Q19", dtype, "bgk", res, [])
     with pytest.raises(NativeEngineError, match="slab layout"):
         dense._check(dense.lib.lt_slab_enstrophy(dense._handle, None, 1.0, 1.0, None, None))
+
+
+@pytest.mark.parametrize("lat,dt,res,masked", [("D3Q19", "f32", [512, 512, 512], False), ("D3Q27", "f64", [320, 320, 256], False),
+                                               ("D3Q27", "f32", [384, 384, 384], True)],
+                         ids=["d3q19-f32-512^3-10GiB", "d3q27-f64-5.7GB", "d3q27-f32-masked-6.1GB"])
+def test_population_buffers_beyond_4_gib(lat, dt, res, masked):
+    """Maximum sizes: population buffers of 5.7-10.2 GB, i.e. byte offsets beyond 2^32 within one tensor (32-bit node
+    indices per population, 64-bit population offsets -- DESIGN section 3).  Size-independent properties: the fused
+    kernels against collide + stream through the operator entry points, two updates per launch against one (where the
+    lattice / dtype has the kernel) bit for bit, mass conserved, and the LAST population's last plane really moved
+    (an offset that wrapped at 4 GiB would leave it or clobber a low address)."""
+    L = orc.LATTICES[lat]
+    dtype = TORCH_DT[dt]
+    torch.manual_seed(5)
+    w = torch.rand(L.q, 1, 1, 1, device="cuda", dtype=dtype) * 0.03 + 0.02
+    f0 = torch.empty([L.q] + res, device="cuda", dtype=dtype)
+    for q in range(L.q):                                  # plane-wise: no second buffer of the same size for rand()
+        f0[q] = w[q] * (1 + 0.05 * torch.rand(res, device="cuda", dtype=dtype))
+    assert f0.numel() * f0.element_size() > 5 * 2 ** 30
+    entries = []
+    if masked:
+        entries = [{"kind": "bounce_back"}]
+    plan = plan_for(lat, dtype, "bgk", res, entries)
+    if masked:
+        ncm = torch.zeros(res, dtype=torch.uint8, device="cuda")
+        ncm[res[0] - 9:res[0] - 3, 5:11, res[2] - 8:res[2] - 2] = 1          # a block near the END of the buffer
+        nsm = torch.zeros([L.q] + res, dtype=torch.uint8, device="cuda")
+        plan.set_masks(ncm, nsm)
+        del nsm
+    mass0 = float(plan.mass(f0))
+    tau, n = 0.6, 4
+    # (1) n steps, one update per launch
+    plan.set_two_step(0)
+    one, other = plan.run(f0.clone(), torch.empty_like(f0), tau, n)
+    assert plan.last_run_info()["two_step_launches"] == 0
+    del other
+    # (2) the same by the operator entry points: collide, stream, n times
+    c, d = f0.clone(), torch.empty_like(f0)
+    for _ in range(n):
+        plan.collide(c, d, tau)
+        plan.stream(d, c)
+    del d
+    assert torch.equal(one, c), "fused launches != collide + stream beyond 4 GiB"
+    del c
+    # (3) two updates per launch where the kernel exists
+    plan2 = plan_for(lat, dtype, "bgk", res, entries)
+    if masked:
+        plan2.set_masks(ncm, torch.zeros([L.q] + res, dtype=torch.uint8, device="cuda"))
+    plan2.set_two_step(1)
+    two, other = plan2.run(f0.clone(), torch.empty_like(f0), tau, n)
+    del other
+    info = plan2.last_run_info()
+    if (lat == "D3Q27" and dt == "f64") or masked:
+        # no fp64 D3Q27 two-step kernel; and the masked two-step kernel addresses through buffer resources with 32-bit
+        # offsets, so plans with masks beyond 4 GiB keep the one-step kernel (api.hip, two_step_possible): same results
+        assert info["two_step_launches"] == 0
+    else:
+        assert info["two_step_launches"] >= 1, info
+    assert torch.equal(two, one), "two updates per launch != one beyond 4 GiB"
+    # (4) conservation (periodic, bounce-back) and the far end of the buffer
+    assert float(plan.mass(two)) == pytest.approx(mass0, rel=1e-6 if dt == "f32" else 1e-13)
+    assert not torch.equal(two[-1, -1], f0[-1, -1])
+    assert bool(torch.isfinite(two[-1]).all()) and bool(torch.isfinite(two[0]).all())
