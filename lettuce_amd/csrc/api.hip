@@ -405,11 +405,17 @@ TwoStepTile two_step_tile(const lt_plan *p) {
 // The 3-D two-step kernels address with 32-bit byte offsets: lbm2_kernel within a plane, lbm2m_kernel (buffer
 // instructions) within the whole field -- the rule of unit.inc's launch_twice / launch_twice_masked, which return
 // kNoKernel beyond it.  Asked BEFORE a plan is put on the two-step path, so that lt_run falls back to the one-step
-// kernel instead of failing at the first launch (Obstacle D3Q19 fp32 at 384^3 is 4.0 GiB).
-bool two_step_addressable(int d, int q, int esize, long long n0, long long n1, long long n2, bool masked) {
+// kernel instead of failing at the first launch (Obstacle D3Q19 fp32 at 384^3 is 4.0 GiB).  With BGK in the reference
+// layout lbm2m_kernel has, for D3Q15 / D3Q19, a second instantiation with one buffer descriptor per population (BIG):
+// there a POPULATION must stay below 4 GiB, not the field.
+bool two_step_addressable(int d, int q, int esize, long long n0, long long n1, long long n2, bool masked,
+                          bool per_population = false) {
   if (d != 3) return true;
-  if (masked) return (long long)q * n0 * n1 * n2 * esize < (1ll << 32);
+  if (masked) return (per_population ? 1ll : (long long)q) * n0 * n1 * n2 * esize < (1ll << 32);
   return n0 * n1 * esize < (1ll << 32);
+}
+bool masked_big_exists(int layout, int collision, int q) {
+  return layout == LT_LAYOUT_REFERENCE && collision == LT_COLLISION_BGK && q <= 19;      // unit.inc, kHasBig
 }
 
 // planes per workgroup of the two-step kernel.  One workgroup occupies a CU (150 KB of LDS), so the
@@ -686,10 +692,11 @@ bool two_step_possible(lt_plan *p, const char **why) {
   }
   // with masks the whole (padded) field is addressed with 32-bit offsets
   const long long widest = std::max(pop_stride_of(p), p->resident != 0 ? resident_stride(p) : 0ll);
-  if (!two_step_addressable(p->unit.d, p->unit.q, p->esize, p->n0, p->n1, p->n2, p->masked != 0) ||
-      (p->masked && p->unit.d == 3 && (long long)p->unit.q * widest * p->esize >= (1ll << 32))) {
-    *why = p->masked ? "with boundaries the two-step kernel addresses the field with 32-bit offsets: q * nodes * sizeof(scalar) "
-                       "must stay below 4 GiB"
+  const bool big = masked_big_exists(p->desc.layout, p->desc.collision, p->unit.q);
+  if (!two_step_addressable(p->unit.d, p->unit.q, p->esize, p->n0, p->n1, p->n2, p->masked != 0, big) ||
+      (p->masked && p->unit.d == 3 && (big ? 1ll : (long long)p->unit.q) * widest * p->esize >= (1ll << 32))) {
+    *why = p->masked ? "with boundaries the two-step kernel addresses with 32-bit offsets: q * nodes * sizeof(scalar) (BGK, "
+                       "reference layout: nodes * sizeof(scalar)) must stay below 4 GiB"
                      : "a plane of the grid exceeds the two-step kernel's 32-bit in-plane offsets";
     return false;
   }
@@ -1613,7 +1620,9 @@ int lt_two_step_limits(const lt_plan_desc *d, int32_t masked, int32_t *tile_widt
   const TwoStepTile tile = unit.d >= 2 ? two_step_tile_of(unit.d, unit.q, esize, (int)e0, masked != 0) : TwoStepTile{0, 0};
   if (tile_width) *tile_width = tile.width;
   if (tile_rows) *tile_rows = tile.rows;
-  if (addressable) *addressable = two_step_addressable(unit.d, unit.q, esize, e0, e1, e2, masked != 0) ? 1 : 0;
+  if (addressable)
+    *addressable = two_step_addressable(unit.d, unit.q, esize, e0, e1, e2, masked != 0,
+                                        masked_big_exists(d->layout, d->collision, unit.q)) ? 1 : 0;
   return LT_OK;
 }
 int lt_slab_two_step_message_blocks(lt_plan *p, int32_t *blocks) {

@@ -31,7 +31,9 @@
 // Memory side (differs from lbm2_kernel because boundary code needs registers: lbm2_kernel + masks spilled):
 //  * buffer addressing: `buffer_load/store_dword v, voffset, s[desc], soffset` with one descriptor per
 //    field, soffset = the plane (uniform), voffset = a per-thread loop constant (population + in-plane
-//    offset, 32 bits): no address arithmetic in the loop.  Fields of 4 GiB and more are refused;
+//    offset, 32 bits): no address arithmetic in the loop.  Fields of 4 GiB and more run the BIG instantiation: one
+//    descriptor per POPULATION, formed on the scalar unit next to each access (base + q * population stride), the
+//    population term leaves voffset -- populations of 4 GiB and more are refused;
 //  * roles per wave on scalar registers: waves that hold output nodes run a loop with phases A and B, the
 //    others a loop with phase A only, and phase B has no exec test (its waves are full), so that every
 //    copy of the loop issues ONE sequence of memory operations per interval and hipcc's `s_waitcnt
@@ -109,7 +111,8 @@ __device__ __forceinline__ MaskedPlanInfo masked_plan_info(const KParams<T> &p) 
 }
 
 // AX: memory axis of the outlet's normal, 2 or 0 (plans without an outlet run the AX = 2 kernel)
-template <typename T, class S, int LAYOUT, int COLL, int T0_, int T1, int AX = 2>
+// BIG: fields of 4 GiB and more (see "Memory side" above)
+template <typename T, class S, int LAYOUT, int COLL, int T0_, int T1, int AX = 2, bool BIG = false>
 __global__ void __launch_bounds__((TwoStep<T, S, T0_, T1>::THREADS))
 lbm2m_kernel(const KParams<T> p, const int seg_len) {
   static_assert(AX == 0 || AX == 2, "outlet along the sweep axis or along the rows");
@@ -151,7 +154,9 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   const int s = p.p_begin + b * seg_len;           // first output plane of this workgroup
 
   const bool in_a = tid < NI;
-  const unsigned pop_bytes = (unsigned)(p.Ni * (long long)sizeof(T)), pop_bytes_out = (unsigned)(p.No * (long long)sizeof(T));
+  // BIG: the population's share of an address is in its descriptor (in_of / out_of below), not in the 32-bit offsets
+  const unsigned pop_bytes = BIG ? 0u : (unsigned)(p.Ni * (long long)sizeof(T)),
+                 pop_bytes_out = BIG ? 0u : (unsigned)(p.No * (long long)sizeof(T));
   const MaskedPlanInfo info = masked_plan_info(p);
   if (tid < kEqCached * S::Q) {
     const int c = tid / S::Q, slot = c == 0 ? info.eq0 : info.eq1;
@@ -200,8 +205,27 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
   }
   const unsigned plane_nodes = (unsigned)p.n1 * (unsigned)p.n0;
   const unsigned plane_bytes = plane_nodes * (unsigned)sizeof(T);
-  const __amdgpu_buffer_rsrc_t in_r = field_rsrc(p.in, (unsigned)S::Q * pop_bytes),
-                               out_r = field_rsrc(p.out, (unsigned)S::Q * pop_bytes_out);
+  const __amdgpu_buffer_rsrc_t in_r = field_rsrc(p.in, BIG ? 0u : (unsigned)S::Q * pop_bytes),
+                               out_r = field_rsrc(p.out, BIG ? 0u : (unsigned)S::Q * pop_bytes_out);
+  // BIG: descriptor of population q AT the plane with byte offset `soff` (the plane goes into the base, soffset is 0:
+  // a descriptor that does not depend on the plane is hoisted out of the sweep -- 2 x Q of them, four scalar registers
+  // each, 520-570 scalar spills -- while this one is four scalar instructions next to its access)
+  auto load_from = [&](auto qc, unsigned voffset, unsigned soff) __attribute__((always_inline)) {
+    if constexpr (BIG) {
+      const T *base = reinterpret_cast<const T *>(reinterpret_cast<const char *>(p.in + (long long)decltype(qc)::value * p.Ni) + soff);
+      return BufIO<T>::load(field_rsrc(base, plane_bytes), voffset, 0u);
+    } else {
+      return BufIO<T>::load(in_r, voffset, soff);
+    }
+  };
+  auto store_to = [&](auto qc, T v, unsigned voffset, unsigned soff) __attribute__((always_inline)) {
+    if constexpr (BIG) {
+      T *base = reinterpret_cast<T *>(reinterpret_cast<char *>(p.out + (long long)decltype(qc)::value * p.No) + soff);
+      BufIO<T>::store_nt(v, field_rsrc(base, plane_bytes), voffset, 0u);
+    } else {
+      BufIO<T>::store_nt(v, out_r, voffset, soff);
+    }
+  };
   const bool abb_a2 = AX == 2 && info.abb_slot != 0;                  // outlet at a plane of the sweep axis
   const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int nbr_lane = (lane - info.abb_side) & 63;                    // AX = 0: who holds the node next to mine
@@ -291,12 +315,20 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
           // an a0 outlet node keeps the populations entering through the outlet: voff[q] already points at
           // the node within a plane, and the plane is its own instead of the one below / above
           const bool keep = a_out && e0 == -info.abb_side;
-          pre[q][0] = BufIO<T>::load(in_r, voff[q] + (keep ? off0 : (e2 > 0 ? offm : offp)), 0u);
+          if constexpr (BIG) {
+            // (the plane is a per-lane choice here: the one case where it has to ride in voffset -- of a descriptor
+            // that spans the population)
+            const T *base = p.in + (long long)q * p.Ni;
+            pre[q][0] = BufIO<T>::load(field_rsrc(base, (unsigned)(p.Ni * (long long)sizeof(T))),
+                                       voff[q] + (keep ? off0 : (e2 > 0 ? offm : offp)), 0u);
+          } else {
+            pre[q][0] = BufIO<T>::load(in_r, voff[q] + (keep ? off0 : (e2 > 0 ? offm : offp)), 0u);
+          }
         } else if constexpr (e2 < 0) {
           const unsigned v = keep_down ? a_own * (unsigned)sizeof(T) + (unsigned)q * pop_bytes : voff[q];
-          pre[q][0] = BufIO<T>::load(in_r, v, offp);
+          pre[q][0] = load_from(qc, v, offp);
         } else {
-          pre[q][0] = BufIO<T>::load(in_r, voff[q], e2 == 0 ? off0 : offm);
+          pre[q][0] = load_from(qc, voff[q], e2 == 0 ? off0 : offm);
         }
       });
     }
@@ -374,7 +406,7 @@ lbm2m_kernel(const KParams<T> p, const int seg_len) {
     const unsigned off = (unsigned)uniform((int)((unsigned)k2 * plane_bytes));
     static_for<S::Q>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
-      BufIO<T>::store_nt(f[q][0], out_r, out_off[q], off);
+      store_to(qc, f[q][0], out_off[q], off);
     });
   };
 

@@ -1,6 +1,7 @@
 """MLUPS of the other BASELINE.json configurations through the lettuce-style API (single GPU):
 cfg1 TGV2D D2Q9 128^2 fp64, cfg4 Obstacle3D D3Q27 256^3 KBC fp32 (inlet + ABB outlet + sphere
-bounce-back), cfg5's per-GPU slab (periodic shear D3Q19 384x384x96 fp64).  One JSON line each."""
+bounce-back), cfg5's per-GPU slab (periodic shear D3Q19 384x384x96 fp64).  One JSON line each.
+usage: bench_configs.py [res=N] [cfg1 cfg4 cfg4bgk cfg4bgk1 obst19 obst19_1 cfg5]   (res: edge of the Obstacle cube, 256)"""
 import sys, os, json, time, io, contextlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -45,7 +46,8 @@ def report(name, flow, sim, dt, fused_ms, steps, bytes_per_node):
                       "bytes_per_node_and_update": bytes_per_node, "kernel": sim._native.plan.kernel_name()}), flush=True)
 
 def main():
-    which = sys.argv[1:] or ["cfg1", "cfg4", "cfg5", "cfg4bgk"]
+    edge = ([int(a[4:]) for a in sys.argv[1:] if a.startswith("res=")] or [256])[0]
+    which = [a for a in sys.argv[1:] if not a.startswith("res=")] or ["cfg1", "cfg4", "cfg5", "cfg4bgk"]
     if "cfg1" in which:
         ctx = lt.Context("cuda:0", torch.float64, True)
         flow = lt.TaylorGreenVortex(ctx, [128, 128], 100, 0.05, lt.D2Q9())
@@ -59,7 +61,7 @@ def main():
                                          ("obst19_1", "bgk", lt.D3Q19, 0)):
         if tag not in which: continue
         ctx = lt.Context("cuda:0", torch.float32, True)
-        flow = lt.Obstacle(ctx, [256, 256, 256], 100, 0.1, domain_length_x=4, stencil=stencil())
+        flow = lt.Obstacle(ctx, [edge] * 3, 100, 0.1, domain_length_x=4, stencil=stencil())
         x, y, z = flow.grid
         flow.mask = ((x - 1) ** 2 + (y - 2) ** 2 + (z - 2) ** 2) < 0.5 ** 2
         flow.initialize()
@@ -69,7 +71,7 @@ def main():
         sim._native.plan.set_two_step(two_step)
         dt, ms = timed(sim, 10, 100)
         q = stencil().q
-        report(f"{tag}: Obstacle3D D3Q{q} 256^3 {coll.upper()} fp32, inlet+ABB outlet+sphere BB"
+        report(f"{tag}: Obstacle3D D3Q{q} {edge}^3 {coll.upper()} fp32, inlet+ABB outlet+sphere BB"
                + (" (one update per launch forced)" if two_step == 0 else ""), flow, sim, dt, ms, 100, 8 * q + 1)
         residency_ab(sim)
         u = flow.u()
