@@ -290,8 +290,9 @@ def test_library_exports_every_declared_symbol(engine_library):
 def test_two_step_admission_by_descriptor_knows_the_4_gib_limit(engine_library):
     """a plan with boundaries whose field reaches 4 GiB must not be put on the two-step path (its
     kernel addresses the field with 32-bit offsets); the rule lt_run / lt_plan_two_step_admitted apply is a
-    descriptor-only query, checked here without a device: Obstacle D3Q19 fp32 at 384^3 (4.0 GiB) and D3Q27 fp64 at
-    272^3 are refused with masks and fine without, 256^3 is fine either way."""
+    descriptor-only query, checked here without a device: D3Q27 fp32 at 344^3 and D3Q27 fp64 at 272^3 are refused with
+    masks, D3Q19 slabs of 4 GiB too; 256^3 is fine either way; Obstacle D3Q19 fp32 at 384^3 (4.0 GiB) is fine since
+    round 4 (a descriptor per population)."""
     from lettuce_amd import _native
     lib = _native.load_library()
     c = _native.ctypes
@@ -306,7 +307,12 @@ def test_two_step_admission_by_descriptor_knows_the_4_gib_limit(engine_library):
         assert lib.lt_two_step_limits(c.byref(d), int(masked), c.byref(w), c.byref(r), c.byref(ok)) == 0, lib.lt_last_error()
         return w.value, r.value, bool(ok.value)
     assert limits("D3Q19", torch.float32, [256] * 3, True) == (64, 8, True)
-    assert limits("D3Q19", torch.float32, [384] * 3, True) == (64, 8, False)      # 19 * 384^3 * 4 B = 4.01 GiB
+    # 19 * 384^3 * 4 B = 4.01 GiB: D3Q15 / D3Q19 BGK in the reference layout has the instantiation with a descriptor per
+    # population (round 4), where one POPULATION must stay below 4 GiB; other collisions, D3Q27 and slabs keep the field rule
+    assert limits("D3Q19", torch.float32, [384] * 3, True) == (64, 8, True)
+    assert limits("D3Q19", torch.float32, [1024, 1024, 1020], True) == (64, 8, True)       # 3.98 GiB per population
+    assert limits("D3Q19", torch.float32, [1024, 1024, 1024], True) == (64, 8, False)
+    assert limits("D3Q27", torch.float32, [344, 344, 344], True)[2] is False               # 27 * 344^3 * 4 B = 4.09 GiB
     assert limits("D3Q19", torch.float32, [384] * 3, False) == (64, 8, True)
     assert limits("D3Q19", torch.float32, [376, 384, 384], True)[2]                # 3.93 GiB
     assert limits("D3Q27", torch.float32, [256] * 3, True) == (64, 4, True)
