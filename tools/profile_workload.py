@@ -11,9 +11,10 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 dev = torch.device("cuda:0")
 if which == "cfg2":
     ctx = lt.Context(dev, torch.float32, True)
-    flow = lt.TaylorGreenVortex(ctx, [256] * 3, 1600, 0.1, lt.D3Q19())
+    edge = int(os.environ.get("LT_PROFILE_EDGE", "256"))          # other sizes: tools/pmc_tlb.sh
+    flow = lt.TaylorGreenVortex(ctx, [edge] * 3, 1600, 0.1, lt.D3Q19())
     sim = lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])
-    q, esize, key = 19, 4, "tgv3d_d3q19_bgk_f32_256"
+    q, esize, key = 19, 4, f"tgv3d_d3q19_bgk_f32_{edge}"
 elif which in ("cfg4", "cfg4bgk", "obst19"):
     ctx = lt.Context(dev, torch.float32, True)
     stencil = lt.D3Q19() if which == "obst19" else lt.D3Q27()
