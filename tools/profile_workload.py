@@ -12,9 +12,10 @@ dev = torch.device("cuda:0")
 if which == "cfg2":
     ctx = lt.Context(dev, torch.float32, True)
     edge = int(os.environ.get("LT_PROFILE_EDGE", "256"))          # other sizes: tools/pmc_tlb.sh
-    flow = lt.TaylorGreenVortex(ctx, [edge] * 3, 1600, 0.1, lt.D3Q19())
+    shape = [int(v) for v in os.environ["LT_PROFILE_RES"].split(",")] if os.environ.get("LT_PROFILE_RES") else [edge] * 3
+    flow = lt.TaylorGreenVortex(ctx, shape, 1600, 0.1, lt.D3Q19())
     sim = lt.Simulation(flow, lt.BGKCollision(flow.units.relaxation_parameter_lu), [])
-    q, esize, key = 19, 4, f"tgv3d_d3q19_bgk_f32_{edge}"
+    q, esize, key = 19, 4, "tgv3d_d3q19_bgk_f32_" + "x".join(str(v) for v in shape)
 elif which in ("cfg4", "cfg4bgk", "obst19"):
     ctx = lt.Context(dev, torch.float32, True)
     stencil = lt.D3Q19() if which == "obst19" else lt.D3Q27()
